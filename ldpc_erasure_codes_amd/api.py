@@ -1,0 +1,307 @@
+"""ctypes binding of the C ABI (include/ldpc_erasure_amd.h -> libldpc_erasure_amd.so).
+
+Host-side mirror of the reference's interfaces for the hot path, so that tests read like the reference's
+own harnesses:
+
+    Context()                        ~ init_opencl()            OpenCL/host/src/main.cpp:439
+    Context.close()                  ~ cleanup()                main.cpp:668
+    Context.decode(...)              ~ My_LDPC_HybridML_NonBinary_Erasure_Decoder(recv, Vlist, Clist, H, n, k, ...)
+                                       Matlab/My_LDPC_HybridML_NonBinary_Erasure_Decoder.m:4   (batched)
+    Context.rs_decode(...)           ~ My_RS_Decode(recv_vec_ind, recv_vec_gf256_val, m, n, k, ...)
+                                       Matlab/My_RS_Decode.m:14                                   (batched)
+
+There is NO CPU fallback here: if the HIP library is missing or no gfx950 device is present every call
+raises.  Arrays may be numpy (host pointers; the library stages them) or torch CUDA tensors (device
+pointers; asynchronous on the context's stream).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libldpc_erasure_amd.so")
+
+OK = 0
+DEVICE_PTRS = 1
+ST_MP_DONE, ST_ML_SOLVED, ST_ML_RANKDEF, ST_ML_SKIPPED = 0, 1, 2, 3
+
+# every symbol include/ldpc_erasure_amd.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "ldpc_amd_init", "ldpc_amd_cleanup", "ldpc_amd_last_error", "ldpc_amd_set_stream", "ldpc_amd_synchronize",
+    "ldpc_amd_code_params", "ldpc_amd_load_builtin_code", "ldpc_amd_register_code", "ldpc_amd_code_info",
+    "ldpc_amd_code_csr", "ldpc_amd_decode_batch", "ldpc_amd_encode_batch", "ldpc_amd_rs_create",
+    "ldpc_amd_rs_generator", "ldpc_amd_rs_encode_batch", "ldpc_amd_rs_decode_batch", "ldpc_amd_synth_source",
+    "ldpc_amd_synth_erasures_uniform", "ldpc_amd_data_in", "ldpc_amd_ldpc_erasure_decoder", "ldpc_amd_data_out",
+    "ldpc_amd_set_profiling", "ldpc_amd_get_profile", "ldpc_amd_selftest", "ldpc_amd_gf_tables", "ldpc_amd_version",
+]
+
+
+class LdpcAmdError(RuntimeError):
+    pass
+
+
+class ErrorType(C.Structure):
+    _fields_ = [("num_LDPC_errors", C.c_int), ("num_RS_errors", C.c_int)]
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libldpc_erasure_amd.so (built in-tree by __graft_entry__.build()).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LdpcAmdError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64
+    L.ldpc_amd_init.argtypes = [i32, C.POINTER(vp)]
+    L.ldpc_amd_cleanup.argtypes = [vp]
+    L.ldpc_amd_cleanup.restype = None
+    L.ldpc_amd_last_error.argtypes = [vp]
+    L.ldpc_amd_last_error.restype = C.c_char_p
+    L.ldpc_amd_set_stream.argtypes = [vp, vp]
+    L.ldpc_amd_synchronize.argtypes = [vp]
+    L.ldpc_amd_code_params.argtypes = [i32, C.POINTER(i32)]
+    L.ldpc_amd_load_builtin_code.argtypes = [vp, i32, u64]
+    L.ldpc_amd_register_code.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.ldpc_amd_code_info.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.ldpc_amd_code_csr.argtypes = [vp, i32, vp, vp, vp]
+    L.ldpc_amd_decode_batch.argtypes = [vp, i32, i32, i64, vp, vp, i32, i32, vp, vp, vp, vp, C.c_uint]
+    L.ldpc_amd_encode_batch.argtypes = [vp, i32, i32, i64, vp, vp, C.c_uint]
+    L.ldpc_amd_rs_create.argtypes = [vp, i32, i32]
+    L.ldpc_amd_rs_generator.argtypes = [vp, i32, vp]
+    L.ldpc_amd_rs_encode_batch.argtypes = [vp, i32, i32, i64, vp, vp, C.c_uint]
+    L.ldpc_amd_rs_decode_batch.argtypes = [vp, i32, i32, i64, vp, vp, vp, C.c_uint]
+    L.ldpc_amd_synth_source.argtypes = [vp, u64, i64, i64, i32, i32, vp]
+    L.ldpc_amd_synth_erasures_uniform.argtypes = [vp, u64, i64, i64, i32, C.c_double, vp]
+    L.ldpc_amd_data_in.argtypes = [vp, vp, C.c_ushort, i32, i32, i32, C.c_long]
+    L.ldpc_amd_ldpc_erasure_decoder.argtypes = [vp, C.c_short, i32]
+    L.ldpc_amd_data_out.argtypes = [vp, vp, i32, C.c_long, C.POINTER(ErrorType)]
+    L.ldpc_amd_set_profiling.argtypes = [vp, i32]
+    L.ldpc_amd_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
+    L.ldpc_amd_selftest.argtypes = [vp]
+    L.ldpc_amd_gf_tables.argtypes = [vp, vp]
+    L.ldpc_amd_version.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def gf_tables():
+    """(mult[256,256], inv[256]) the kernels use -- host computation, no GPU needed."""
+    L = load_library()
+    mult = np.zeros((256, 256), dtype=np.uint8)
+    inv = np.zeros(256, dtype=np.uint8)
+    L.ldpc_amd_gf_tables(mult.ctypes.data, inv.ctypes.data)
+    return mult, inv
+
+
+def code_params(code_ind):
+    L = load_library()
+    p = (C.c_int * 6)()
+    if L.ldpc_amd_code_params(code_ind, p) != OK:
+        raise LdpcAmdError(f"no built-in code {code_ind}")
+    return list(p)
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if _is_torch(x):
+        assert x.is_contiguous()
+        return x.data_ptr()
+    assert x.flags["C_CONTIGUOUS"]
+    return x.ctypes.data
+
+
+class Context:
+    def __init__(self, device=0):
+        self._L = load_library()
+        h = C.c_void_p()
+        rc = self._L.ldpc_amd_init(device, C.byref(h))
+        if rc != OK:
+            raise LdpcAmdError(f"ldpc_amd_init({device}) = {rc}: {self._L.ldpc_amd_last_error(None).decode()}")
+        self._h = h
+        self.device = device
+
+    # -- life-cycle
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ldpc_amd_cleanup(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise LdpcAmdError(f"{what} = {rc}: {self._L.ldpc_amd_last_error(self._h).decode()}")
+        return rc
+
+    def set_stream(self, stream_handle):
+        self._check(self._L.ldpc_amd_set_stream(self._h, C.c_void_p(stream_handle)), "set_stream")
+
+    def synchronize(self):
+        self._check(self._L.ldpc_amd_synchronize(self._h), "synchronize")
+
+    def set_profiling(self, enable):
+        self._check(self._L.ldpc_amd_set_profiling(self._h, int(bool(enable))), "set_profiling")
+
+    def get_profile(self):
+        """{'peel': (ms, launches), 'apply': ..., 'ml': ...} since the last call (synchronises)."""
+        ms = (C.c_double * 3)()
+        cnt = (C.c_int64 * 3)()
+        self._check(self._L.ldpc_amd_get_profile(self._h, ms, cnt), "get_profile")
+        return {name: (ms[i], cnt[i]) for i, name in enumerate(("peel", "apply", "ml"))}
+
+    def selftest(self):
+        self._check(self._L.ldpc_amd_selftest(self._h), "selftest")
+
+    # -- codes
+    def load_builtin_code(self, code_ind, coef_seed):
+        return self._check(self._L.ldpc_amd_load_builtin_code(self._h, code_ind, coef_seed), "load_builtin_code")
+
+    def register_code(self, code):
+        rp = np.ascontiguousarray(code.row_ptr, dtype=np.uint32)
+        cols = np.ascontiguousarray(code.cols, dtype=np.uint16)
+        coefs = np.ascontiguousarray(code.coefs, dtype=np.uint8)
+        return self._check(self._L.ldpc_amd_register_code(self._h, code.n, code.k, rp.ctypes.data, cols.ctypes.data,
+                                                          coefs.ctypes.data), "register_code")
+
+    def code_info(self, code):
+        n, k, nnz = C.c_int(), C.c_int(), C.c_int()
+        self._check(self._L.ldpc_amd_code_info(self._h, code, C.byref(n), C.byref(k), C.byref(nnz)), "code_info")
+        return n.value, k.value, nnz.value
+
+    def code_csr(self, code):
+        n, k, nnz = self.code_info(code)
+        rp = np.zeros(n - k + 1, dtype=np.uint32)
+        cols = np.zeros(nnz, dtype=np.uint16)
+        coefs = np.zeros(nnz, dtype=np.uint8)
+        self._check(self._L.ldpc_amd_code_csr(self._h, code, rp.ctypes.data, cols.ctypes.data, coefs.ctypes.data), "code_csr")
+        return rp, cols, coefs
+
+    # -- hot path
+    def decode(self, code, sym, erased, max_sweeps=10, do_ml=1, out=None, sweeps=None, residual=None, status=None):
+        """sym [F,n,S] (or [F,n] for S=1) uint8, erased [F,n] uint8.
+        numpy in -> numpy out (synchronous).  torch CUDA tensors in -> torch out (asynchronous).
+        Returns (out, sweeps, residual, status)."""
+        n, k, _ = self.code_info(code)
+        dev = _is_torch(sym)
+        F = sym.shape[0]
+        S = 1 if sym.ndim == 2 else sym.shape[2]
+        assert sym.shape[1] == n and tuple(erased.shape) == (F, n)
+        if dev:
+            import torch
+            mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=sym.device)  # noqa: E731
+            out = mk(tuple(sym.shape), torch.uint8) if out is None else out
+            sweeps = mk((F,), torch.int32) if sweeps is None else sweeps
+            residual = mk((F,), torch.int32) if residual is None else residual
+            status = mk((F,), torch.int32) if status is None else status
+        else:
+            sym = np.ascontiguousarray(sym, dtype=np.uint8)
+            erased = np.ascontiguousarray(erased, dtype=np.uint8)
+            out = np.empty_like(sym) if out is None else out
+            sweeps = np.empty(F, dtype=np.int32) if sweeps is None else sweeps
+            residual = np.empty(F, dtype=np.int32) if residual is None else residual
+            status = np.empty(F, dtype=np.int32) if status is None else status
+        self._check(self._L.ldpc_amd_decode_batch(self._h, code, S, F, _ptr(sym), _ptr(erased), max_sweeps, do_ml,
+                                                  _ptr(out), _ptr(sweeps), _ptr(residual), _ptr(status),
+                                                  DEVICE_PTRS if dev else 0), "decode_batch")
+        return out, sweeps, residual, status
+
+    def encode(self, code, source, out=None):
+        """source [F,k,S] (or [F,k]) -> codeword [F,n,S] (or [F,n])."""
+        n, k, _ = self.code_info(code)
+        dev = _is_torch(source)
+        F = source.shape[0]
+        S = 1 if source.ndim == 2 else source.shape[2]
+        assert source.shape[1] == k
+        shape = (F, n) if source.ndim == 2 else (F, n, S)
+        if dev:
+            import torch
+            out = torch.empty(shape, dtype=torch.uint8, device=source.device) if out is None else out
+        else:
+            source = np.ascontiguousarray(source, dtype=np.uint8)
+            out = np.empty(shape, dtype=np.uint8) if out is None else out
+        self._check(self._L.ldpc_amd_encode_batch(self._h, code, S, F, _ptr(source), _ptr(out), DEVICE_PTRS if dev else 0),
+                    "encode_batch")
+        return out
+
+    # -- Reed-Solomon
+    def rs_create(self, n, k):
+        return self._check(self._L.ldpc_amd_rs_create(self._h, n, k), "rs_create")
+
+    def rs_generator(self, rs, n, k):
+        g = np.zeros((k, n), dtype=np.uint8)
+        self._check(self._L.ldpc_amd_rs_generator(self._h, rs, g.ctypes.data), "rs_generator")
+        return g
+
+    def rs_encode(self, rs, n, k, source):
+        dev = _is_torch(source)
+        B = source.shape[0]
+        S = 1 if source.ndim == 2 else source.shape[2]
+        shape = (B, n) if source.ndim == 2 else (B, n, S)
+        if dev:
+            import torch
+            out = torch.empty(shape, dtype=torch.uint8, device=source.device)
+        else:
+            source = np.ascontiguousarray(source, dtype=np.uint8)
+            out = np.empty(shape, dtype=np.uint8)
+        self._check(self._L.ldpc_amd_rs_encode_batch(self._h, rs, S, B, _ptr(source), _ptr(out), DEVICE_PTRS if dev else 0),
+                    "rs_encode_batch")
+        return out
+
+    def rs_decode(self, rs, recv_idx, recv_val):
+        """recv_idx [B,k] uint16 (0-based ascending), recv_val [B,k,S] or [B,k] -> msg like recv_val."""
+        dev = _is_torch(recv_val)
+        B = recv_val.shape[0]
+        S = 1 if recv_val.ndim == 2 else recv_val.shape[2]
+        if dev:
+            import torch
+            msg = torch.empty_like(recv_val)
+        else:
+            recv_idx = np.ascontiguousarray(recv_idx, dtype=np.uint16)
+            recv_val = np.ascontiguousarray(recv_val, dtype=np.uint8)
+            msg = np.empty_like(recv_val)
+        self._check(self._L.ldpc_amd_rs_decode_batch(self._h, rs, S, B, _ptr(recv_idx), _ptr(recv_val), _ptr(msg),
+                                                     DEVICE_PTRS if dev else 0), "rs_decode_batch")
+        return msg
+
+    # -- synthetic inputs on the device (torch tensors)
+    def synth_source(self, seed, frame0, nframes, k, S, out):
+        self._check(self._L.ldpc_amd_synth_source(self._h, seed, frame0, nframes, k, S, _ptr(out)), "synth_source")
+        return out
+
+    def synth_erasures_uniform(self, seed, frame0, nframes, n, per, out):
+        self._check(self._L.ldpc_amd_synth_erasures_uniform(self._h, seed, frame0, nframes, n, float(per), _ptr(out)),
+                    "synth_erasures_uniform")
+        return out
+
+    # -- FPGA harness trio (OpenCL/host/src/main.cpp:578-626)
+    def data_in(self, nldpc, seed, per_numerator_div_64, code_ind, num_frames):
+        self._check(self._L.ldpc_amd_data_in(self._h, None, nldpc, seed, per_numerator_div_64, code_ind, num_frames), "data_in")
+
+    def ldpc_erasure_decoder(self, num_iter, code_ind):
+        self._check(self._L.ldpc_amd_ldpc_erasure_decoder(self._h, num_iter, code_ind), "ldpc_erasure_decoder")
+
+    def data_out(self, code_ind, num_frames):
+        st = ErrorType()
+        self._check(self._L.ldpc_amd_data_out(self._h, None, code_ind, num_frames, C.byref(st)), "data_out")
+        return st.num_LDPC_errors, st.num_RS_errors

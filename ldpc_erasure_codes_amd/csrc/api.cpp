@@ -1,0 +1,733 @@
+// api.cpp -- the C ABI of include/ldpc_erasure_amd.h (host side only; kernels live in kernels.hip).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#include "internal.h"
+#include "../../include/ldpc_erasure_amd_synth.h"
+
+namespace ldpc_amd {
+
+// ------------------------------------------------------------------------------------------------
+// GF(256) host tables (poly 0x171)
+// ------------------------------------------------------------------------------------------------
+const GfHost &gf_host()
+{
+    static GfHost g;
+    static bool built = false;
+    if (!built) {
+        memset(&g, 0, sizeof(g));
+        int x = 1;
+        for (int i = 0; i < 255; i++) {
+            g.exp[i] = (uint8_t)x;
+            g.log[x] = (uint8_t)i;
+            x <<= 1;
+            if (x & 0x100) x ^= kPrimPoly;
+        }
+        for (int i = 255; i < 512; i++) g.exp[i] = g.exp[i - 255];
+        g.inv[0] = 0;
+        for (int a = 1; a < 256; a++) g.inv[a] = g.exp[(255 - g.log[a]) % 255];
+        built = true;
+    }
+    return g;
+}
+
+void build_mul3_tables(uint32_t *tab)
+{
+    const GfHost &g = gf_host();
+    for (int c = 0; c < 256; c++) {
+        uint8_t b[32] = {0};
+        for (int i = 0; i < 8; i++) b[i] = g.mul((uint8_t)c, (uint8_t)i);               // bits 0-2
+        for (int i = 0; i < 8; i++) b[8 + i] = g.mul((uint8_t)c, (uint8_t)(i << 3));    // bits 3-5
+        for (int i = 0; i < 4; i++) b[16 + i] = g.mul((uint8_t)c, (uint8_t)(i << 6));   // bits 6-7
+        for (int w = 0; w < 8; w++)
+            tab[c * 8 + w] = (uint32_t)b[4 * w] | ((uint32_t)b[4 * w + 1] << 8) | ((uint32_t)b[4 * w + 2] << 16) |
+                             ((uint32_t)b[4 * w + 3] << 24);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// errors, scratch
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_init_error;
+
+int set_error(ldpc_amd_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else g_init_error = buf;
+    return code;
+}
+
+int scratch_reserve(ldpc_amd_ctx *ctx, Scratch &s, size_t bytes)
+{
+    if (bytes <= s.cap) return LDPC_AMD_OK;
+    if (s.p) {
+        // pending work may still use the old block
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return set_error(ctx, LDPC_AMD_EHIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
+        (void)hipFree(s.p);
+        s.p = nullptr;
+        s.cap = 0;
+    }
+    size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    hipError_t e = hipMalloc(&s.p, want);
+    if (e != hipSuccess) {
+        s.p = nullptr;
+        return set_error(ctx, LDPC_AMD_ENOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    s.cap = want;
+    return LDPC_AMD_OK;
+}
+
+static hipEvent_t prof_take(ldpc_amd_ctx *ctx)
+{
+    hipEvent_t e = nullptr;
+    if (!ctx->prof_pool.empty()) {
+        e = ctx->prof_pool.back();
+        ctx->prof_pool.pop_back();
+    } else if (hipEventCreate(&e) != hipSuccess) {
+        e = nullptr;
+    }
+    return e;
+}
+
+hipEvent_t prof_begin(ldpc_amd_ctx *ctx)
+{
+    if (!ctx->profiling) return nullptr;
+    hipEvent_t e = prof_take(ctx);
+    if (e) (void)hipEventRecord(e, ctx->stream);
+    return e;
+}
+
+void prof_end(ldpc_amd_ctx *ctx, int kind, hipEvent_t start)
+{
+    if (!start) return;
+    hipEvent_t e = prof_take(ctx);
+    if (!e) { ctx->prof_pool.push_back(start); return; }
+    (void)hipEventRecord(e, ctx->stream);
+    ctx->prof_events[kind].emplace_back(start, e);
+}
+
+static void scratch_free(Scratch &s)
+{
+    if (s.p) (void)hipFree(s.p);
+    s.p = nullptr;
+    s.cap = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// built-in code ROM
+// ------------------------------------------------------------------------------------------------
+struct BuiltinCode {
+    int code_ind, n, k, first_row, last_row, rs_n, rs_k, nnz;
+    const uint32_t *row_ptr;
+    const uint16_t *cols;
+};
+#include "builtin_codes_gen.inc"
+
+static const BuiltinCode *find_builtin(int code_ind)
+{
+    for (const BuiltinCode &b : kBuiltinCodes)
+        if (b.code_ind == code_ind) return &b;
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// code registration: CSR -> device tables
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+static int upload(ldpc_amd_ctx *ctx, HostCode *hc, const std::vector<T> &v, const T **dst)
+{
+    void *p = nullptr;
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return set_error(ctx, LDPC_AMD_ENOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    hc->allocs.push_back(p);
+    if (!v.empty()) {
+        e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return set_error(ctx, LDPC_AMD_EHIP, "hipMemcpy: %s", hipGetErrorString(e));
+    }
+    *dst = (const T *)p;
+    return LDPC_AMD_OK;
+}
+
+static void free_code(HostCode *hc)
+{
+    if (!hc) return;
+    for (void *p : hc->allocs) (void)hipFree(p);
+    delete hc;
+}
+
+static int register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_ptr, const uint16_t *cols,
+                         const uint8_t *coefs)
+{
+    if (!row_ptr || !cols) return set_error(ctx, LDPC_AMD_EINVAL, "null code arrays");
+    if (n <= 1 || k < 1 || k >= n || n > 65534) return set_error(ctx, LDPC_AMD_EINVAL, "bad (n,k) = (%d,%d)", n, k);
+    const int m = n - k;
+    if (row_ptr[0] != 0) return set_error(ctx, LDPC_AMD_EINVAL, "row_ptr[0] != 0");
+    const GfHost &gf = gf_host();
+    HostCode *hc = new (std::nothrow) HostCode();
+    if (!hc) return set_error(ctx, LDPC_AMD_ENOMEM, "out of host memory");
+    hc->n = n; hc->k = k; hc->m = m; hc->nnz = (int)row_ptr[m];
+    hc->row_ptr.assign(row_ptr, row_ptr + m + 1);
+    hc->cols.assign(cols, cols + hc->nnz);
+    if (coefs) hc->coefs.assign(coefs, coefs + hc->nnz);
+    else hc->coefs.assign(hc->nnz, 1);
+    int maxdeg = 0;
+    for (int r = 0; r < m; r++) {
+        if (row_ptr[r + 1] < row_ptr[r]) { delete hc; return set_error(ctx, LDPC_AMD_EINVAL, "row_ptr not monotone at row %d", r); }
+        const int d = (int)(row_ptr[r + 1] - row_ptr[r]);
+        maxdeg = std::max(maxdeg, d);
+        int prev = -1;
+        for (uint32_t e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
+            if ((int)cols[e] <= prev || cols[e] >= n) { delete hc; return set_error(ctx, LDPC_AMD_EINVAL, "row %d: columns must be ascending and < n", r); }
+            if (hc->coefs[e] == 0) { delete hc; return set_error(ctx, LDPC_AMD_EINVAL, "row %d: zero coefficient", r); }
+            prev = cols[e];
+        }
+    }
+    if (maxdeg > 24) { delete hc; return set_error(ctx, LDPC_AMD_EUNSUP, "row degree %d > 24 not supported", maxdeg); }
+    hc->maxdeg = maxdeg;
+    const int degpad = maxdeg <= 8 ? 8 : (maxdeg <= 16 ? 16 : 24);
+    const int mpad = (m + 63) / 64 * 64;
+
+    std::vector<uint32_t> edges(hc->nnz);
+    for (int e = 0; e < hc->nnz; e++)
+        edges[e] = (uint32_t)cols[e] | ((uint32_t)hc->coefs[e] << 16) | ((uint32_t)gf.log[hc->coefs[e]] << 24);
+    std::vector<uint16_t> ell_col((size_t)degpad * mpad, 0xFFFF);
+    std::vector<uint8_t> ell_logc((size_t)degpad * mpad, 0);
+    for (int r = 0; r < m; r++)
+        for (uint32_t e = row_ptr[r], t = 0; e < row_ptr[r + 1]; e++, t++) {
+            ell_col[(size_t)t * mpad + r] = cols[e];
+            ell_logc[(size_t)t * mpad + r] = gf.log[hc->coefs[e]];
+        }
+
+    // static encode schedule: row i solves column k+i (triangle form) once the parity symbols among its other
+    // neighbours are known.  Only valid when the code is in triangle form; otherwise encode is refused.
+    std::vector<uint32_t> enc_steps;
+    std::vector<uint16_t> enc_lvlend;
+    int enc_nlevels = 0;
+    {
+        bool triangle = true;
+        std::vector<int> lvl(m, 0);
+        for (int r = 0; r < m && triangle; r++) {
+            if (row_ptr[r + 1] == row_ptr[r] || cols[row_ptr[r + 1] - 1] != k + r) { triangle = false; break; }
+            int L = 0;
+            for (uint32_t e = row_ptr[r]; e + 1 < row_ptr[r + 1]; e++)
+                if (cols[e] >= k) L = std::max(L, lvl[cols[e] - k]);
+            lvl[r] = L + 1;
+            enc_nlevels = std::max(enc_nlevels, L + 1);
+        }
+        if (triangle) {
+            enc_lvlend.assign(enc_nlevels + 1, 0);
+            for (int r = 0; r < m; r++) enc_lvlend[lvl[r]]++;
+            std::vector<uint32_t> start(enc_nlevels + 2, 0);
+            for (int L = 1; L <= enc_nlevels; L++) start[L + 1] = start[L] + enc_lvlend[L];
+            enc_steps.assign(m, 0);
+            std::vector<uint32_t> fill(start);
+            for (int r = 0; r < m; r++) enc_steps[fill[lvl[r]]++] = (uint32_t)r | ((uint32_t)(k + r) << 16);
+            enc_lvlend[0] = 0;
+            for (int L = 1; L <= enc_nlevels; L++) enc_lvlend[L] = (uint16_t)start[L + 1];
+        } else {
+            enc_nlevels = 0;
+            enc_steps.assign(1, 0);
+            enc_lvlend.assign(1, 0);
+        }
+    }
+
+    DevCode &d = hc->dev;
+    d.n = n; d.k = k; d.m = m; d.nnz = hc->nnz; d.maxdeg = maxdeg; d.degpad = degpad; d.mpad = mpad;
+    d.enc_nlevels = enc_nlevels;
+    int rc;
+    if ((rc = upload(ctx, hc, hc->row_ptr, &d.row_ptr)) || (rc = upload(ctx, hc, edges, &d.edges)) ||
+        (rc = upload(ctx, hc, ell_col, &d.ell_col)) || (rc = upload(ctx, hc, ell_logc, &d.ell_logc)) ||
+        (rc = upload(ctx, hc, enc_steps, &d.enc_steps)) || (rc = upload(ctx, hc, enc_lvlend, &d.enc_lvlend))) {
+        free_code(hc);
+        return rc;
+    }
+    ctx->codes.push_back(hc);
+    return (int)ctx->codes.size() - 1;
+}
+
+static HostCode *get_code(ldpc_amd_ctx *ctx, int code)
+{
+    if (!ctx || code < 0 || code >= (int)ctx->codes.size()) return nullptr;
+    return ctx->codes[code];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-pointer staging
+// ------------------------------------------------------------------------------------------------
+struct Staged {
+    const uint8_t *sym = nullptr;
+    const uint8_t *erased = nullptr;
+    uint8_t *out = nullptr;
+    int32_t *sweeps = nullptr, *residual = nullptr, *status = nullptr;
+};
+
+}  // namespace ldpc_amd
+
+using namespace ldpc_amd;
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+const char *ldpc_amd_version(void) { return "ldpc_erasure_amd 0.1 (gfx950)"; }
+
+int ldpc_amd_init(int device_ordinal, ldpc_amd_ctx **out)
+{
+    if (!out) return set_error(nullptr, LDPC_AMD_EINVAL, "ctx output pointer is null");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return set_error(nullptr, LDPC_AMD_EHIP, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device_ordinal < 0 || device_ordinal >= ndev)
+        return set_error(nullptr, LDPC_AMD_EINVAL, "device ordinal %d out of range (0..%d)", device_ordinal, ndev - 1);
+    if ((e = hipSetDevice(device_ordinal)) != hipSuccess)
+        return set_error(nullptr, LDPC_AMD_EHIP, "hipSetDevice: %s", hipGetErrorString(e));
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_ordinal)) != hipSuccess)
+        return set_error(nullptr, LDPC_AMD_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return set_error(nullptr, LDPC_AMD_EUNSUP, "device %d is %s; this library is built for gfx950 only",
+                         device_ordinal, prop.gcnArchName);
+    ldpc_amd_ctx *ctx = new (std::nothrow) ldpc_amd_ctx();
+    if (!ctx) return set_error(nullptr, LDPC_AMD_ENOMEM, "out of host memory");
+    ctx->device = device_ordinal;
+    ctx->sm_count = prop.multiProcessorCount;
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
+        delete ctx;
+        return set_error(nullptr, LDPC_AMD_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    ctx->own_stream = true;
+    if ((e = upload_constants(ctx->stream)) != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return set_error(nullptr, LDPC_AMD_EHIP, "constant upload: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return LDPC_AMD_OK;
+}
+
+void ldpc_amd_cleanup(ldpc_amd_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (HostCode *c : ctx->codes) free_code(c);
+    for (HostRs *r : ctx->rs) {
+        if (r->d_g) (void)hipFree(r->d_g);
+        if (r->d_pt) (void)hipFree(r->d_pt);
+        delete r;
+    }
+    Scratch *all[] = {&ctx->sched, &ctx->mlws, &ctx->mlstate, &ctx->mllist, &ctx->stage_in, &ctx->stage_er,
+                      &ctx->stage_out, &ctx->stage_i32, &ctx->rsws, &ctx->fpga_erased, &ctx->fpga_stats};
+    for (Scratch *s : all) scratch_free(*s);
+    for (auto &v : ctx->prof_events)
+        for (auto &pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *ldpc_amd_last_error(const ldpc_amd_ctx *ctx) { return ctx ? ctx->err.c_str() : g_init_error.c_str(); }
+
+int ldpc_amd_set_stream(ldpc_amd_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return LDPC_AMD_EINVAL;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_synchronize(ldpc_amd_ctx *ctx)
+{
+    if (!ctx) return LDPC_AMD_EINVAL;
+    LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_code_params(int code_ind, int params[6])
+{
+    const BuiltinCode *b = find_builtin(code_ind);
+    if (!b || !params) return LDPC_AMD_ENOCODE;
+    params[0] = b->n; params[1] = b->k; params[2] = b->first_row; params[3] = b->last_row;
+    params[4] = b->rs_n; params[5] = b->rs_k;
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_load_builtin_code(ldpc_amd_ctx *ctx, int code_ind, uint64_t coef_seed)
+{
+    if (!ctx) return LDPC_AMD_EINVAL;
+    const BuiltinCode *b = find_builtin(code_ind);
+    if (!b) return set_error(ctx, LDPC_AMD_ENOCODE, "no built-in code with index %d", code_ind);
+    std::vector<uint8_t> coefs(b->nnz, 1);
+    if (coef_seed)
+        for (int i = 0; i < b->nnz; i++) coefs[i] = ldpc_synth_nonzero(coef_seed, LDPC_SYNTH_STREAM_COEF, (uint64_t)i);
+    return register_code(ctx, b->n, b->k, b->row_ptr, b->cols, coefs.data());
+}
+
+int ldpc_amd_register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_ptr, const uint16_t *cols,
+                           const uint8_t *coefs)
+{
+    if (!ctx) return LDPC_AMD_EINVAL;
+    return register_code(ctx, n, k, row_ptr, cols, coefs);
+}
+
+int ldpc_amd_code_info(ldpc_amd_ctx *ctx, int code, int *n, int *k, int *nnz)
+{
+    HostCode *hc = get_code(ctx, code);
+    if (!hc) return ctx ? set_error(ctx, LDPC_AMD_ENOCODE, "unknown code handle %d", code) : LDPC_AMD_EINVAL;
+    if (n) *n = hc->n;
+    if (k) *k = hc->k;
+    if (nnz) *nnz = hc->nnz;
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_code_csr(ldpc_amd_ctx *ctx, int code, uint32_t *row_ptr, uint16_t *cols, uint8_t *coefs)
+{
+    HostCode *hc = get_code(ctx, code);
+    if (!hc) return ctx ? set_error(ctx, LDPC_AMD_ENOCODE, "unknown code handle %d", code) : LDPC_AMD_EINVAL;
+    if (row_ptr) memcpy(row_ptr, hc->row_ptr.data(), hc->row_ptr.size() * sizeof(uint32_t));
+    if (cols) memcpy(cols, hc->cols.data(), hc->cols.size() * sizeof(uint16_t));
+    if (coefs) memcpy(coefs, hc->coefs.data(), hc->coefs.size());
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_decode_batch(ldpc_amd_ctx *ctx, int code, int S, int64_t nframes, const uint8_t *sym,
+                          const uint8_t *erased, int max_sweeps, int do_ml, uint8_t *out, int32_t *sweeps,
+                          int32_t *residual, int32_t *status, unsigned flags)
+{
+    HostCode *hc = get_code(ctx, code);
+    if (!hc) return ctx ? set_error(ctx, LDPC_AMD_ENOCODE, "unknown code handle %d", code) : LDPC_AMD_EINVAL;
+    if (nframes < 0 || S < 1) return set_error(ctx, LDPC_AMD_EINVAL, "bad nframes/S");
+    if (nframes == 0) return LDPC_AMD_OK;
+    if (!sym || !erased || !out) return set_error(ctx, LDPC_AMD_EINVAL, "sym/erased/out must not be null");
+    LDPC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t fbytes = (size_t)hc->n * S;
+    DecodeArgs d{};
+    d.code = hc->dev; d.S = S; d.nframes = nframes; d.in_rows = hc->n; d.max_sweeps = max_sweeps; d.do_ml = do_ml ? 1 : 0;
+    if (flags & LDPC_AMD_DEVICE_PTRS) {
+        d.sym = sym; d.erased = erased; d.out = out; d.sweeps = sweeps; d.residual = residual; d.status = status;
+        return launch_decode(ctx, d);
+    }
+    int rc;
+    if ((rc = scratch_reserve(ctx, ctx->stage_in, fbytes * nframes)) || (rc = scratch_reserve(ctx, ctx->stage_er, (size_t)hc->n * nframes)) ||
+        (rc = scratch_reserve(ctx, ctx->stage_out, fbytes * nframes)) || (rc = scratch_reserve(ctx, ctx->stage_i32, 3 * sizeof(int32_t) * (size_t)nframes)))
+        return rc;
+    LDPC_HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_in.p, sym, fbytes * nframes, hipMemcpyHostToDevice, ctx->stream));
+    LDPC_HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_er.p, erased, (size_t)hc->n * nframes, hipMemcpyHostToDevice, ctx->stream));
+    int32_t *i32 = (int32_t *)ctx->stage_i32.p;
+    d.sym = (const uint8_t *)ctx->stage_in.p; d.erased = (const uint8_t *)ctx->stage_er.p; d.out = (uint8_t *)ctx->stage_out.p;
+    d.sweeps = i32; d.residual = i32 + nframes; d.status = i32 + 2 * nframes;
+    if ((rc = launch_decode(ctx, d))) return rc;
+    LDPC_HIP_TRY(ctx, hipMemcpyAsync(out, d.out, fbytes * nframes, hipMemcpyDeviceToHost, ctx->stream));
+    if (sweeps) LDPC_HIP_TRY(ctx, hipMemcpyAsync(sweeps, d.sweeps, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, ctx->stream));
+    if (residual) LDPC_HIP_TRY(ctx, hipMemcpyAsync(residual, d.residual, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, ctx->stream));
+    if (status) LDPC_HIP_TRY(ctx, hipMemcpyAsync(status, d.status, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, ctx->stream));
+    LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_encode_batch(ldpc_amd_ctx *ctx, int code, int S, int64_t nframes, const uint8_t *source,
+                          uint8_t *codeword, unsigned flags)
+{
+    HostCode *hc = get_code(ctx, code);
+    if (!hc) return ctx ? set_error(ctx, LDPC_AMD_ENOCODE, "unknown code handle %d", code) : LDPC_AMD_EINVAL;
+    if (nframes < 0 || S < 1) return set_error(ctx, LDPC_AMD_EINVAL, "bad nframes/S");
+    if (nframes == 0) return LDPC_AMD_OK;
+    if (!source || !codeword) return set_error(ctx, LDPC_AMD_EINVAL, "source/codeword must not be null");
+    if (hc->dev.enc_nlevels == 0) return set_error(ctx, LDPC_AMD_EUNSUP, "code is not in triangle form: no systematic encoder");
+    LDPC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (flags & LDPC_AMD_DEVICE_PTRS) return launch_encode(ctx, hc->dev, S, nframes, source, codeword);
+    const size_t ib = (size_t)hc->k * S * nframes, ob = (size_t)hc->n * S * nframes;
+    int rc;
+    if ((rc = scratch_reserve(ctx, ctx->stage_in, ib)) || (rc = scratch_reserve(ctx, ctx->stage_out, ob))) return rc;
+    LDPC_HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_in.p, source, ib, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_encode(ctx, hc->dev, S, nframes, (const uint8_t *)ctx->stage_in.p, (uint8_t *)ctx->stage_out.p))) return rc;
+    LDPC_HIP_TRY(ctx, hipMemcpyAsync(codeword, ctx->stage_out.p, ob, hipMemcpyDeviceToHost, ctx->stream));
+    LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return LDPC_AMD_OK;
+}
+
+// ---- Reed-Solomon ----------------------------------------------------------------------------------
+static int gf_invert(const GfHost &gf, std::vector<uint8_t> &A, int k, std::vector<uint8_t> &I)
+{
+    I.assign((size_t)k * k, 0);
+    for (int i = 0; i < k; i++) I[(size_t)i * k + i] = 1;
+    for (int col = 0; col < k; col++) {
+        int p = -1;
+        for (int r = col; r < k; r++)
+            if (A[(size_t)r * k + col]) { p = r; break; }
+        if (p < 0) return -1;
+        if (p != col)
+            for (int t = 0; t < k; t++) {
+                std::swap(A[(size_t)col * k + t], A[(size_t)p * k + t]);
+                std::swap(I[(size_t)col * k + t], I[(size_t)p * k + t]);
+            }
+        const uint8_t iv = gf.inv[A[(size_t)col * k + col]];
+        for (int t = 0; t < k; t++) {
+            A[(size_t)col * k + t] = gf.mul(A[(size_t)col * k + t], iv);
+            I[(size_t)col * k + t] = gf.mul(I[(size_t)col * k + t], iv);
+        }
+        for (int r = 0; r < k; r++) {
+            const uint8_t f = A[(size_t)r * k + col];
+            if (r == col || !f) continue;
+            for (int t = 0; t < k; t++) {
+                A[(size_t)r * k + t] ^= gf.mul(f, A[(size_t)col * k + t]);
+                I[(size_t)r * k + t] ^= gf.mul(f, I[(size_t)col * k + t]);
+            }
+        }
+    }
+    return 0;
+}
+
+int ldpc_amd_rs_create(ldpc_amd_ctx *ctx, int n, int k)
+{
+    if (!ctx) return LDPC_AMD_EINVAL;
+    if (n < 2 || n > 255 || k < 1 || k >= n) return set_error(ctx, LDPC_AMD_EINVAL, "bad RS (n,k) = (%d,%d)", n, k);
+    const GfHost &gf = gf_host();
+    // Matlab/Test_My_RS_Decode.m:30-37: G(row,col) = alpha^(row*col) (1-based), G <- inv(G(1:k,1:k)) * G
+    std::vector<uint8_t> V((size_t)k * n), A((size_t)k * k), I;
+    for (int row = 1; row <= k; row++)
+        for (int col = 1; col <= n; col++) V[(size_t)(row - 1) * n + col - 1] = gf.exp[(row * col) % 255];
+    for (int r = 0; r < k; r++) memcpy(&A[(size_t)r * k], &V[(size_t)r * n], k);
+    if (gf_invert(gf, A, k, I)) return set_error(ctx, LDPC_AMD_EINVAL, "singular Vandermonde block");
+    HostRs *rs = new (std::nothrow) HostRs();
+    if (!rs) return set_error(ctx, LDPC_AMD_ENOMEM, "out of host memory");
+    rs->n = n; rs->k = k;
+    rs->g.assign((size_t)k * n, 0);
+    for (int r = 0; r < k; r++)
+        for (int c = 0; c < n; c++) {
+            uint8_t s = 0;
+            for (int t = 0; t < k; t++) s ^= gf.mul(I[(size_t)r * k + t], V[(size_t)t * n + c]);
+            rs->g[(size_t)r * n + c] = s;
+        }
+    std::vector<uint8_t> pt((size_t)(n - k) * k);
+    for (int j = 0; j < n - k; j++)
+        for (int i = 0; i < k; i++) pt[(size_t)j * k + i] = rs->g[(size_t)i * n + k + j];
+    hipError_t e;
+    if ((e = hipMalloc((void **)&rs->d_g, rs->g.size())) != hipSuccess || (e = hipMalloc((void **)&rs->d_pt, pt.size())) != hipSuccess ||
+        (e = hipMemcpy(rs->d_g, rs->g.data(), rs->g.size(), hipMemcpyHostToDevice)) != hipSuccess ||
+        (e = hipMemcpy(rs->d_pt, pt.data(), pt.size(), hipMemcpyHostToDevice)) != hipSuccess) {
+        if (rs->d_g) (void)hipFree(rs->d_g);
+        if (rs->d_pt) (void)hipFree(rs->d_pt);
+        delete rs;
+        return set_error(ctx, LDPC_AMD_EHIP, "RS table upload: %s", hipGetErrorString(e));
+    }
+    ctx->rs.push_back(rs);
+    return (int)ctx->rs.size() - 1;
+}
+
+static HostRs *get_rs(ldpc_amd_ctx *ctx, int rs)
+{
+    if (!ctx || rs < 0 || rs >= (int)ctx->rs.size()) return nullptr;
+    return ctx->rs[rs];
+}
+
+int ldpc_amd_rs_generator(ldpc_amd_ctx *ctx, int rs, uint8_t *g)
+{
+    HostRs *r = get_rs(ctx, rs);
+    if (!r || !g) return ctx ? set_error(ctx, LDPC_AMD_ENOCODE, "unknown RS handle %d", rs) : LDPC_AMD_EINVAL;
+    memcpy(g, r->g.data(), r->g.size());
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_rs_encode_batch(ldpc_amd_ctx *ctx, int rs, int S, int64_t nblocks, const uint8_t *source,
+                             uint8_t *codeword, unsigned flags)
+{
+    HostRs *r = get_rs(ctx, rs);
+    if (!r) return ctx ? set_error(ctx, LDPC_AMD_ENOCODE, "unknown RS handle %d", rs) : LDPC_AMD_EINVAL;
+    if (nblocks < 0 || (S != 1 && S % 16)) return set_error(ctx, LDPC_AMD_EUNSUP, "S must be 1 or a multiple of 16");
+    if (nblocks == 0) return LDPC_AMD_OK;
+    if (!source || !codeword) return set_error(ctx, LDPC_AMD_EINVAL, "null data pointer");
+    LDPC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (flags & LDPC_AMD_DEVICE_PTRS) return launch_rs_encode(ctx, *r, S, nblocks, source, codeword);
+    const size_t ib = (size_t)r->k * S * nblocks, ob = (size_t)r->n * S * nblocks;
+    int rc;
+    if ((rc = scratch_reserve(ctx, ctx->stage_in, ib)) || (rc = scratch_reserve(ctx, ctx->stage_out, ob))) return rc;
+    LDPC_HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_in.p, source, ib, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_rs_encode(ctx, *r, S, nblocks, (const uint8_t *)ctx->stage_in.p, (uint8_t *)ctx->stage_out.p))) return rc;
+    LDPC_HIP_TRY(ctx, hipMemcpyAsync(codeword, ctx->stage_out.p, ob, hipMemcpyDeviceToHost, ctx->stream));
+    LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_rs_decode_batch(ldpc_amd_ctx *ctx, int rs, int S, int64_t nblocks, const uint16_t *recv_idx,
+                             const uint8_t *recv_val, uint8_t *msg, unsigned flags)
+{
+    HostRs *r = get_rs(ctx, rs);
+    if (!r) return ctx ? set_error(ctx, LDPC_AMD_ENOCODE, "unknown RS handle %d", rs) : LDPC_AMD_EINVAL;
+    if (nblocks < 0 || (S != 1 && S % 16)) return set_error(ctx, LDPC_AMD_EUNSUP, "S must be 1 or a multiple of 16");
+    if (nblocks == 0) return LDPC_AMD_OK;
+    if (!recv_idx || !recv_val || !msg) return set_error(ctx, LDPC_AMD_EINVAL, "null data pointer");
+    LDPC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (flags & LDPC_AMD_DEVICE_PTRS) return launch_rs_decode(ctx, *r, S, nblocks, recv_idx, recv_val, msg);
+    const size_t vb = (size_t)r->k * S * nblocks, xb = (size_t)r->k * 2 * nblocks;
+    int rc;
+    if ((rc = scratch_reserve(ctx, ctx->stage_in, vb)) || (rc = scratch_reserve(ctx, ctx->stage_er, xb)) ||
+        (rc = scratch_reserve(ctx, ctx->stage_out, vb)))
+        return rc;
+    LDPC_HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_in.p, recv_val, vb, hipMemcpyHostToDevice, ctx->stream));
+    LDPC_HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_er.p, recv_idx, xb, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = launch_rs_decode(ctx, *r, S, nblocks, (const uint16_t *)ctx->stage_er.p, (const uint8_t *)ctx->stage_in.p,
+                               (uint8_t *)ctx->stage_out.p)))
+        return rc;
+    LDPC_HIP_TRY(ctx, hipMemcpyAsync(msg, ctx->stage_out.p, vb, hipMemcpyDeviceToHost, ctx->stream));
+    LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return LDPC_AMD_OK;
+}
+
+// ---- synthetic inputs --------------------------------------------------------------------------------
+int ldpc_amd_synth_source(ldpc_amd_ctx *ctx, uint64_t seed, int64_t frame0, int64_t nframes, int k, int S,
+                          uint8_t *d_source)
+{
+    if (!ctx || !d_source || nframes < 0 || k < 1 || S < 1) return ctx ? set_error(ctx, LDPC_AMD_EINVAL, "bad argument") : LDPC_AMD_EINVAL;
+    LDPC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch_synth_source(ctx, seed, frame0, nframes, k, S, d_source);
+}
+
+int ldpc_amd_synth_erasures_uniform(ldpc_amd_ctx *ctx, uint64_t seed, int64_t frame0, int64_t nframes, int n,
+                                    double per, uint8_t *d_erased)
+{
+    if (!ctx || !d_erased || nframes < 0 || n < 1) return ctx ? set_error(ctx, LDPC_AMD_EINVAL, "bad argument") : LDPC_AMD_EINVAL;
+    LDPC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch_synth_erasures(ctx, seed, LDPC_SYNTH_STREAM_ERASE, frame0 * n, nframes * n, ldpc_synth_threshold(per), d_erased);
+}
+
+// ---- FPGA harness drop-in (three kernels of OpenCL/host/src/main.cpp:578-626) ---------------------------
+static int fpga_code(ldpc_amd_ctx *ctx, int code_ind)
+{
+    if (code_ind < 0 || code_ind >= 4) return set_error(ctx, LDPC_AMD_ENOCODE, "code_ind %d out of range", code_ind);
+    if (ctx->fpga_binary_code[code_ind] < 0) {
+        int h = ldpc_amd_load_builtin_code(ctx, code_ind, 0);  // binary H: the FPGA decoder XORs packets
+        if (h < 0) return h;
+        ctx->fpga_binary_code[code_ind] = h;
+    }
+    return ctx->fpga_binary_code[code_ind];
+}
+
+int ldpc_amd_data_in(ldpc_amd_ctx *ctx, const ldpc_amd_symbol_type *data_in, unsigned short nldpc, int seed,
+                     int PER_numerator_div_64, int code_ind, long numFrames)
+{
+    (void)data_in;  // the FPGA kernel never reads its buffer either (ldpc_erasure_decoder_top.cl:84-117)
+    if (!ctx) return LDPC_AMD_EINVAL;
+    const BuiltinCode *b = find_builtin(code_ind);
+    if (!b) return set_error(ctx, LDPC_AMD_ENOCODE, "no built-in code with index %d", code_ind);
+    if (numFrames < 0) return set_error(ctx, LDPC_AMD_EINVAL, "numFrames < 0");
+    (void)nldpc;  // the kernel takes n from ldpc_params[code_ind] (ldpc_erasure_decoder_top.cl:70-71), nldpc is only printed
+    LDPC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = scratch_reserve(ctx, ctx->fpga_erased, (size_t)std::max<long>(numFrames, 1) * b->n))) return rc;
+    ctx->fpga_frames = numFrames; ctx->fpga_code_ind = code_ind; ctx->fpga_per64 = PER_numerator_div_64;
+    // erased iff (rv & 0x3F) < PER_numerator_div_64 (:105): probability p/64, drawn here from the synth stream
+    const double per = PER_numerator_div_64 <= 0 ? 0.0 : (PER_numerator_div_64 >= 64 ? 1.0 : PER_numerator_div_64 / 64.0);
+    return launch_synth_erasures(ctx, (uint64_t)(uint32_t)seed, LDPC_SYNTH_STREAM_ERASE, 0, (int64_t)numFrames * b->n,
+                                 ldpc_synth_threshold(per), (uint8_t *)ctx->fpga_erased.p);
+}
+
+int ldpc_amd_ldpc_erasure_decoder(ldpc_amd_ctx *ctx, short num_iter, int code_ind)
+{
+    if (!ctx) return LDPC_AMD_EINVAL;
+    if (ctx->fpga_code_ind != code_ind) return set_error(ctx, LDPC_AMD_EINVAL, "ldpc_amd_data_in was not called for code_ind %d", code_ind);
+    int h = fpga_code(ctx, code_ind);
+    if (h < 0) return h;
+    HostCode *hc = ctx->codes[h];
+    const long nf = ctx->fpga_frames;
+    if (nf == 0) return LDPC_AMD_OK;
+    int rc;
+    if ((rc = scratch_reserve(ctx, ctx->fpga_stats, sizeof(int32_t) * (size_t)(nf + 16)))) return rc;
+    // flags-only decode: the payload is the all-zero codeword, only the erasure pattern matters
+    DecodeArgs d{};
+    d.code = hc->dev; d.S = 16; d.nframes = nf; d.in_rows = hc->n; d.max_sweeps = num_iter; d.do_ml = 0;
+    d.erased = (const uint8_t *)ctx->fpga_erased.p;
+    d.flags_only = 1;
+    d.residual_sys = (int32_t *)ctx->fpga_stats.p + 16;
+    return launch_decode(ctx, d);
+}
+
+int ldpc_amd_data_out(ldpc_amd_ctx *ctx, ldpc_amd_symbol_type *data_out, int code_ind, long numFrames,
+                      ldpc_amd_error_type *stats)
+{
+    if (!ctx) return LDPC_AMD_EINVAL;
+    if (ctx->fpga_code_ind != code_ind || numFrames != ctx->fpga_frames)
+        return set_error(ctx, LDPC_AMD_EINVAL, "data_out arguments do not match the last data_in call");
+    const BuiltinCode *b = find_builtin(code_ind);
+    int h = fpga_code(ctx, code_ind);
+    if (h < 0) return h;
+    HostCode *hc = ctx->codes[h];
+    int32_t host[2] = {0, 0};
+    if (numFrames > 0) {
+        int32_t *dst = (int32_t *)ctx->fpga_stats.p;
+        int rc = launch_fpga_stats(ctx, hc->dev, b->rs_n, b->rs_k, numFrames, (const uint8_t *)ctx->fpga_erased.p, dst + 16, dst);
+        if (rc) return rc;
+        LDPC_HIP_TRY(ctx, hipMemcpyAsync(host, dst, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+        LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    if (stats) { stats->num_LDPC_errors = host[0]; stats->num_RS_errors = host[1]; }
+    if (data_out) {
+        // the FPGA data_out never writes its buffer (ldpc_erasure_decoder_top.cl:140-150 is commented out);
+        // the all-zero codeword is what a correct decode returns.
+        memset(data_out, 0, sizeof(ldpc_amd_symbol_type) * (size_t)b->k);
+    }
+    return LDPC_AMD_OK;
+}
+
+// ---- measurement -----------------------------------------------------------------------------------------
+int ldpc_amd_set_profiling(ldpc_amd_ctx *ctx, int enable)
+{
+    if (!ctx) return LDPC_AMD_EINVAL;
+    ctx->profiling = enable != 0;
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_get_profile(ldpc_amd_ctx *ctx, double ms[LDPC_AMD_PROF_KINDS], int64_t launches[LDPC_AMD_PROF_KINDS])
+{
+    if (!ctx) return LDPC_AMD_EINVAL;
+    LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int kd = 0; kd < LDPC_AMD_PROF_KINDS; kd++) {
+        double total = 0;
+        for (auto &pr : ctx->prof_events[kd]) {
+            float t = 0;
+            if (hipEventElapsedTime(&t, pr.first, pr.second) == hipSuccess) total += t;
+            ctx->prof_pool.push_back(pr.first);
+            ctx->prof_pool.push_back(pr.second);
+        }
+        if (ms) ms[kd] = total;
+        if (launches) launches[kd] = (int64_t)ctx->prof_events[kd].size();
+        ctx->prof_events[kd].clear();
+    }
+    return LDPC_AMD_OK;
+}
+
+// ---- diagnostics ---------------------------------------------------------------------------------------
+int ldpc_amd_selftest(ldpc_amd_ctx *ctx)
+{
+    if (!ctx) return LDPC_AMD_EINVAL;
+    LDPC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch_selftest(ctx);
+}
+
+int ldpc_amd_gf_tables(uint8_t *mult, uint8_t *inv)
+{
+    const GfHost &g = gf_host();
+    if (mult)
+        for (int a = 0; a < 256; a++)
+            for (int b = 0; b < 256; b++) mult[a * 256 + b] = g.mul((uint8_t)a, (uint8_t)b);
+    if (inv) memcpy(inv, g.inv, 256);
+    return LDPC_AMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,148 @@
+// internal.h -- shared between the C-ABI translation unit and the HIP kernel translation units.
+// Not installed; the public interface is include/ldpc_erasure_amd.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/ldpc_erasure_amd.h"
+
+namespace ldpc_amd {
+
+// ---------------------------------------------------------------------------------------------
+// GF(2^8), primitive polynomial x^8+x^6+x^5+x^4+1 = 0x171 (369).  The reference fixes it at
+// Matlab/ErasureCodes_NonBinaryLDPCSim.m:70 ([1 0 1 1 1 0 0 0 1], MSB first) and ships the resulting
+// tables in Matlab/GF_256_add_mult_inv_tables.mat; tests compare ldpc_amd_gf_tables() with that file.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPrimPoly = 0x171;
+
+struct GfHost {
+    uint8_t log[256];   // log[0] unused (0)
+    uint8_t exp[512];   // exp[i] = alpha^(i mod 255)
+    uint8_t inv[256];   // inv[0] = 0
+    uint8_t mul(uint8_t a, uint8_t b) const { return (a && b) ? exp[log[a] + log[b]] : 0; }
+};
+const GfHost &gf_host();
+
+// Per-coefficient byte-permute tables for the packed multiply (see gf256_dev.h): 8 dwords per coefficient.
+void build_mul3_tables(uint32_t *tab /* [256*8] */);
+
+// ---------------------------------------------------------------------------------------------
+// Device view of one LDPC code
+// ---------------------------------------------------------------------------------------------
+struct DevCode {
+    int n, k, m, nnz;
+    int maxdeg;   // largest row degree
+    int degpad;   // template bucket the kernels are instantiated for (8, 16 or 24) >= maxdeg
+    int mpad;     // m rounded up to a multiple of 64
+    const uint32_t *row_ptr;  // [m+1]
+    const uint32_t *edges;    // [nnz]  col | coef << 16 | log(coef) << 24   (CSR order, ascending cols)
+    const uint16_t *ell_col;  // [degpad][mpad]  transposed padded rows, 0xFFFF = none
+    const uint8_t *ell_logc;  // [degpad][mpad]  log(coef)
+    // static encode schedule (all parity symbols erased): rows sorted by dependency level
+    const uint32_t *enc_steps;   // [m] row | (k+row) << 16
+    const uint16_t *enc_lvlend;  // [enc_nlevels+1], [L] = end offset of level L, [0] = 0
+    int enc_nlevels;
+};
+
+struct HostCode {
+    int n = 0, k = 0, m = 0, nnz = 0, maxdeg = 0;
+    std::vector<uint32_t> row_ptr;
+    std::vector<uint16_t> cols;
+    std::vector<uint8_t> coefs;
+    DevCode dev{};
+    std::vector<void *> allocs;
+};
+
+struct HostRs {
+    int n = 0, k = 0;
+    std::vector<uint8_t> g;  // [k][n] systematic generator
+    uint8_t *d_g = nullptr;  // device copy, [k][n]
+    uint8_t *d_pt = nullptr; // device copy of the parity part transposed: [n-k][k]
+};
+
+// Growable device scratch
+struct Scratch {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace ldpc_amd
+
+struct ldpc_amd_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    std::vector<ldpc_amd::HostCode *> codes;
+    std::vector<ldpc_amd::HostRs *> rs;
+    // workspaces
+    ldpc_amd::Scratch sched;    // per-frame schedules (packet path)
+    ldpc_amd::Scratch mlws;     // ML stage matrices
+    ldpc_amd::Scratch mlstate;  // residual erasure masks of the frames handed to the ML stage
+    ldpc_amd::Scratch mllist;   // [1 + nframes] int32: count, frame ids
+    ldpc_amd::Scratch stage_in, stage_er, stage_out, stage_i32;  // host-pointer staging
+    ldpc_amd::Scratch rsws;
+    // FPGA-harness emulation state (ldpc_amd_data_in / _ldpc_erasure_decoder / _data_out)
+    ldpc_amd::Scratch fpga_erased, fpga_stats;
+    long fpga_frames = 0;
+    int fpga_code_ind = -1;
+    int fpga_per64 = 0;
+    int fpga_binary_code[4] = {-1, -1, -1, -1};
+    int sm_count = 256;
+    // profiling (ldpc_amd_set_profiling): event pairs per kernel kind
+    bool profiling = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[LDPC_AMD_PROF_KINDS];
+    std::vector<hipEvent_t> prof_pool;
+};
+
+namespace ldpc_amd {
+
+// ---- launchers implemented in the .hip files (all asynchronous on ctx->stream) -----------------
+struct DecodeArgs {
+    DevCode code;
+    int S;
+    int64_t nframes;
+    const uint8_t *sym;     // [nframes][in_rows][S]
+    const uint8_t *erased;  // [nframes][n] or nullptr (encode mode: rows >= in_rows are erased)
+    int in_rows;            // n (decode) or k (encode)
+    int max_sweeps;
+    int do_ml;
+    uint8_t *out;           // [nframes][n][S]
+    int32_t *sweeps, *residual, *status;  // may be nullptr
+    int flags_only = 0;                   // peel only (no data movement): FPGA-harness statistics
+    int32_t *residual_sys = nullptr;      // [nframes] unknown symbols among the first k, or nullptr
+};
+
+hipError_t upload_constants(hipStream_t s);
+int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &a);
+int launch_encode(ldpc_amd_ctx *ctx, const DevCode &code, int S, int64_t nframes, const uint8_t *src, uint8_t *cw);
+int launch_selftest(ldpc_amd_ctx *ctx);
+int launch_synth_source(ldpc_amd_ctx *ctx, uint64_t seed, int64_t frame0, int64_t nframes, int k, int S, uint8_t *d);
+int launch_synth_erasures(ldpc_amd_ctx *ctx, uint64_t seed, uint32_t stream_id, int64_t first, int64_t count,
+                          uint64_t thresh, uint8_t *d);
+int launch_rs_decode(ldpc_amd_ctx *ctx, const HostRs &rs, int S, int64_t nblocks, const uint16_t *idx,
+                     const uint8_t *val, uint8_t *msg);
+int launch_rs_encode(ldpc_amd_ctx *ctx, const HostRs &rs, int S, int64_t nblocks, const uint8_t *src, uint8_t *cw);
+int launch_fpga_stats(ldpc_amd_ctx *ctx, const DevCode &code, int rs_n, int rs_k, int64_t nframes,
+                      const uint8_t *erased0, const int32_t *residual_k, int32_t *stats /* [2] */);
+
+int scratch_reserve(ldpc_amd_ctx *ctx, Scratch &s, size_t bytes);
+// Brackets one kernel launch with events when profiling is on (no-ops otherwise).
+hipEvent_t prof_begin(ldpc_amd_ctx *ctx);
+void prof_end(ldpc_amd_ctx *ctx, int kind, hipEvent_t start);
+int set_error(ldpc_amd_ctx *ctx, int code, const char *fmt, ...);
+
+#define LDPC_HIP_TRY(ctx, expr)                                                                   \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess)                                                                    \
+            return ldpc_amd::set_error((ctx), LDPC_AMD_EHIP, "%s failed: %s (%s:%d)", #expr,      \
+                                       hipGetErrorString(e__), __FILE__, __LINE__);               \
+    } while (0)
+
+}  // namespace ldpc_amd

@@ -1,0 +1,936 @@
+// kernels.hip -- the single device translation unit of libldpc_erasure_amd.so (gfx950 / CDNA4 only).
+//
+// Hot path of the reference:
+//   a1  in-order message-passing sweeps   Matlab/My_LDPC_HybridML_NonBinary_Erasure_Decoder.m:13-59
+//   a2  rhs build                         ...Decoder.m:63-82
+//   a3  forward elimination               ...Decoder.m:85-115
+//   a4  back substitution + write-back    ...Decoder.m:117-129
+//   a5  RS erasure decode                 Matlab/My_RS_Decode_Optimize_With_GFTables.m:15-118   (rs_kernels.inc)
+//   a8  systematic encoder                Matlab/ErasureCodes_NonBinaryLDPCSim.m:173-182
+//
+// Design (DESIGN.md has the long version):
+//   * The erasure PATTERN of a frame fixes which check solves which symbol and in what order; the symbol
+//     VALUES only ride along.  So every frame is first "peeled" on its erasure flags alone by one wavefront
+//     (exact emulation of the reference's sequential Gauss-Seidel sweep: 64 checks per step, one lane per
+//     check, wave ballot/ffs to pick the next check with exactly one unknown, readlane to broadcast the
+//     solved symbol).  The result is a list of (check, symbol) steps tagged with a dependency level.
+//   * S = 1 (the Matlab model): the same wavefront then applies the steps level by level, one lane per
+//     step, on the codeword held in LDS, with GF(256) log/antilog tables in LDS.
+//   * S >= 16 (packets): a second kernel streams the S-byte rows: every wavefront handles one step at a
+//     time with a wave-uniform coefficient, 16 bytes per lane, v_perm_b32 multiply (gf256_dev.h).
+//   * Residual frames are compacted into a list and solved by the ML kernel (exact pivot order of the
+//     reference, including its behaviour on rank-deficient systems).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "internal.h"
+#include "gf256_dev.h"
+#include "../../include/ldpc_erasure_amd_synth.h"
+
+namespace ldpc_amd {
+
+namespace {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
+
+// Orders LDS traffic between the lanes of ONE wavefront (hardware executes a wave's LDS ops in order;
+// this only stops the compiler from moving accesses across the point).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// =================================================================================================
+// a1: peeling of one frame by one wavefront -- exact in-order (Gauss-Seidel) sweep semantics
+// =================================================================================================
+// Reference loop (...Decoder.m:21-59): for every sweep, for ii = 1..m IN ORDER: count the erased
+// neighbours of check ii in the CURRENT state; if exactly one, solve it (visible to check ii+1 at once).
+// After the sweep stop if no erasure is left among ALL n symbols.
+//
+// Emulation: 64 consecutive checks at a time, lane = check.  cnt / xs (xor of erased neighbour ids) /
+// ml (max level of known neighbours) are computed from the state array at chunk start and then patched
+// for lanes ABOVE a solving lane only -- exactly the visibility rule of the sequential loop.
+//   st[j]   : 0xFFFF erased and unknown, otherwise the dependency level of symbol j (0 = received)
+//   steps[] : (check | symbol << 16) in solve order; slvl[] the step's level (1 + max level of its inputs)
+template <int MAXDEG>
+__device__ __forceinline__ void peel_wave(const uint16_t *ell_col, int mpad, uint16_t *st, uint32_t *steps,
+                                          uint16_t *slvl, int max_sweeps, int &nsteps, int &remaining,
+                                          int &sweeps, int &maxlvl)
+{
+    const int lane = lane_id();
+    const int nchunks = mpad >> 6;
+    nsteps = 0; sweeps = 0; maxlvl = 0;
+    while (sweeps < max_sweeps) {               // :21  while (stopsig==0) && (itestep<itenum)
+        sweeps++;                               // :23
+        for (int ch = 0; ch < nchunks && remaining > 0; ch++) {  // :27 (rows past the last erasure change nothing)
+            const int row = (ch << 6) + lane;
+            uint32_t c[MAXDEG];
+            int cnt = 0;
+            uint32_t xs = 0, ml = 0;
+#pragma unroll
+            for (int t = 0; t < MAXDEG; t++) {  // :30-35
+                c[t] = ell_col[t * mpad + row];
+                if (c[t] != 0xFFFFu) {
+                    const uint32_t s = st[c[t]];
+                    if (s == 0xFFFFu) { cnt++; xs ^= c[t]; }
+                    else ml = max(ml, s);
+                }
+            }
+            uint64_t elig = ~0ull;
+            for (;;) {
+                const uint64_t cand = __ballot(cnt == 1) & elig;  // :37 num_erasures == 1
+                if (cand == 0) break;
+                const int l = __ffsll((long long)cand) - 1;        // first such check in row order
+                const uint32_t e = __builtin_amdgcn_readlane(xs, l);
+                const uint32_t lv = __builtin_amdgcn_readlane(ml, l) + 1u;
+                if (lane == 0) {
+                    st[e] = (uint16_t)lv;                          // :47 y_current(erasure_ind) = ...
+                    steps[nsteps] = (uint32_t)((ch << 6) + l) | (e << 16);
+                    slvl[nsteps] = (uint16_t)lv;
+                }
+                nsteps++; remaining--;
+                maxlvl = max(maxlvl, (int)lv);
+                elig = (l == 63) ? 0ull : (~0ull << (l + 1));
+                bool hit = false;
+#pragma unroll
+                for (int t = 0; t < MAXDEG; t++) hit |= (c[t] == e);
+                if (hit && lane > l) { cnt--; xs ^= e; ml = max(ml, lv); }
+                if (lane == l) cnt = 0;
+            }
+            wave_sync();
+        }
+        if (remaining == 0) break;              // :51-54
+    }
+}
+
+// Counting sort of the steps by level (wavefront-local, LDS).  On return sorted[] holds the steps grouped
+// by level and lvlend[L] (L = 0..maxlvl) is the end offset of level L (lvlend[0] = 0).
+__device__ __forceinline__ void sort_steps_by_level(const uint32_t *steps, const uint16_t *slvl, int nsteps,
+                                                    int maxlvl, uint32_t *lvlend, uint32_t *sorted)
+{
+    const int lane = lane_id();
+    for (int i = lane; i <= maxlvl; i += kWave) lvlend[i] = 0;
+    wave_sync();
+    for (int i = lane; i < nsteps; i += kWave) atomicAdd(&lvlend[slvl[i]], 1u);
+    wave_sync();
+    uint32_t carry = 0;
+    for (int base = 0; base <= maxlvl; base += kWave) {
+        const int idx = base + lane;
+        const uint32_t v = (idx <= maxlvl) ? lvlend[idx] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        if (idx <= maxlvl) lvlend[idx] = incl - v + carry;  // exclusive prefix = start of level idx
+        carry += __shfl(incl, 63);
+    }
+    wave_sync();
+    for (int i = lane; i < nsteps; i += kWave) {
+        const uint32_t pos = atomicAdd(&lvlend[slvl[i]], 1u);  // start -> end while filling
+        sorted[pos] = steps[i];
+    }
+    wave_sync();
+}
+
+// =================================================================================================
+// Kernel A: peel (+ apply when S == 1).  One wavefront per frame, WPB frames per workgroup.
+// =================================================================================================
+struct PeelLds {        // byte offsets into dynamic LDS
+    int ell_col;        // u16 [degpad][mpad]
+    int ell_logc;       // u8  [degpad][mpad]      (S == 1 only)
+    int lg, ex;         // u8 [256], u8 [512]      (S == 1 only)
+    int wave0;          // first per-wave region
+    int wave_stride;
+    // inside a per-wave region
+    int st;             // u16 [n]  later reused as u32 lvlend[maxlvl+1]
+    int y;              // u8  [n]                 (S == 1 only)
+    int steps;          // u32 [m]
+    int slvl;           // u16 [m]
+    int sorted;         // u32 [m]
+    int total;
+};
+
+struct PeelArgs {
+    DevCode code;
+    PeelLds lds;
+    int64_t nframes;
+    const uint8_t *sym;     // S == 1: [nframes][in_rows]
+    const uint8_t *erased;  // [nframes][n] or nullptr
+    int in_rows;
+    int max_sweeps, do_ml;
+    uint8_t *out;           // S == 1: [nframes][n]
+    int32_t *sweeps, *residual, *status;
+    int32_t *residual_sys;  // unknown symbols among the first k (FPGA frame-error criterion), or nullptr
+    // packet path: schedule output
+    uint32_t *sched_hdr;    // [nframes][2]  nsteps, maxlvl
+    uint32_t *sched_steps;  // [nframes][m]
+    uint16_t *sched_lvlend; // [nframes][m+1]
+    // ML hand-off
+    int32_t *ml_list;       // [0] = count, [1..] frame ids
+    uint8_t *ml_state;      // [slot][n]  1 = still erased
+};
+
+template <int MAXDEG, bool FUSED_S1>
+__global__ __launch_bounds__(256) void ldpc_peel_kernel(PeelArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const DevCode &cd = a.code;
+    const int n = cd.n, m = cd.m, mpad = cd.mpad;
+    const int lane = lane_id(), wave = wave_id();
+    const int wpb = (int)(blockDim.x >> 6);
+
+    // ---- code tables -> LDS (shared by the frames of this workgroup)
+    uint16_t *ell_col = reinterpret_cast<uint16_t *>(smem + a.lds.ell_col);
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(cd.ell_col);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(ell_col);
+        const int words = (MAXDEG * mpad) >> 1;
+        for (int i = (int)threadIdx.x; i < words; i += (int)blockDim.x) dst[i] = src[i];
+    }
+    uint8_t *ell_logc = smem + a.lds.ell_logc;
+    uint8_t *lg = smem + a.lds.lg;
+    uint8_t *ex = smem + a.lds.ex;
+    if (FUSED_S1) {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(cd.ell_logc);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(ell_logc);
+        const int words = (MAXDEG * mpad) >> 2;
+        for (int i = (int)threadIdx.x; i < words; i += (int)blockDim.x) dst[i] = src[i];
+        for (int i = (int)threadIdx.x; i < 256; i += (int)blockDim.x) lg[i] = c_log[i];
+        for (int i = (int)threadIdx.x; i < 512; i += (int)blockDim.x) ex[i] = c_exp[i];
+    }
+    __syncthreads();
+
+    const int64_t f = (int64_t)blockIdx.x * wpb + wave;
+    if (f >= a.nframes) return;  // no workgroup barrier below this point
+
+    unsigned char *wbase = smem + a.lds.wave0 + wave * a.lds.wave_stride;
+    uint16_t *st = reinterpret_cast<uint16_t *>(wbase + a.lds.st);
+    uint8_t *y = wbase + a.lds.y;
+    uint32_t *steps = reinterpret_cast<uint32_t *>(wbase + a.lds.steps);
+    uint16_t *slvl = reinterpret_cast<uint16_t *>(wbase + a.lds.slvl);
+    uint32_t *sorted = reinterpret_cast<uint32_t *>(wbase + a.lds.sorted);
+
+    // ---- load the frame's erasure flags (and, for S == 1, its symbols)
+    int remaining = 0;
+    {
+        const uint8_t *er = a.erased ? a.erased + f * n : nullptr;
+        const uint8_t *sy = FUSED_S1 ? a.sym + f * a.in_rows : nullptr;
+        for (int j0 = 0; j0 < n; j0 += kWave) {
+            const int j = j0 + lane;
+            bool e = false;
+            if (j < n) {
+                e = er ? (er[j] != 0) : (j >= a.in_rows);
+                st[j] = e ? (uint16_t)0xFFFFu : (uint16_t)0;
+                if (FUSED_S1) y[j] = (e || j >= a.in_rows) ? (uint8_t)0 : sy[j];
+            }
+            remaining += __popcll(__ballot(e));
+        }
+    }
+    wave_sync();
+
+    int nsteps, sweeps, maxlvl;
+    peel_wave<MAXDEG>(ell_col, mpad, st, steps, slvl, a.max_sweeps, nsteps, remaining, sweeps, maxlvl);
+
+    // ---- per-frame results + hand-off of residual frames to the ML stage
+    int stcode = LDPC_AMD_ST_MP_DONE;
+    if (remaining > 0) {
+        stcode = LDPC_AMD_ST_ML_SKIPPED;
+        if (a.do_ml && remaining <= m) {   // ...Decoder.m:61; E > n-k cannot be written back (:127)
+            int slot = 0;
+            if (lane == 0) {
+                slot = atomicAdd(&a.ml_list[0], 1);
+                a.ml_list[1 + slot] = (int32_t)f;
+            }
+            slot = (int)uniform((uint32_t)slot);
+            uint8_t *ms = a.ml_state + (int64_t)slot * n;
+            for (int j = lane; j < n; j += kWave) ms[j] = (st[j] == 0xFFFFu) ? 1 : 0;
+        }
+    }
+    if (a.residual_sys) {
+        int rs = 0;
+        for (int j0 = 0; j0 < cd.k; j0 += kWave) {
+            const int j = j0 + lane;
+            rs += __popcll(__ballot(j < cd.k && st[j] == 0xFFFFu));
+        }
+        if (lane == 0) a.residual_sys[f] = rs;
+    }
+    if (lane == 0) {
+        if (a.sweeps) a.sweeps[f] = sweeps;      // :130 iterations = itestep
+        if (a.residual) a.residual[f] = remaining;
+        if (a.status) a.status[f] = stcode;
+    }
+    wave_sync();
+
+    // ---- group the steps by dependency level (st is dead from here on: reuse it for the level offsets)
+    uint32_t *lvlend = reinterpret_cast<uint32_t *>(st);
+    sort_steps_by_level(steps, slvl, nsteps, maxlvl, lvlend, sorted);
+
+    if (!FUSED_S1) {
+        if (!a.sched_hdr) return;  // flags-only run
+        if (lane == 0) {
+            a.sched_hdr[2 * f] = (uint32_t)nsteps;
+            a.sched_hdr[2 * f + 1] = (uint32_t)maxlvl;
+        }
+        uint32_t *gs = a.sched_steps + f * m;
+        for (int i = lane; i < nsteps; i += kWave) gs[i] = sorted[i];
+        uint16_t *gl = a.sched_lvlend + f * (m + 1);
+        for (int i = lane; i <= maxlvl; i += kWave) gl[i] = (uint16_t)lvlend[i];
+        return;
+    }
+
+    // ---- S == 1: apply the steps on the LDS-resident codeword, one lane per step, level by level.
+    //      y(e) = inv(H(i,e)) * sum_{j != e} H(i,j) y(j)      (...Decoder.m:39-47)
+    for (int L = 1; L <= maxlvl; L++) {
+        const int s0 = (int)lvlend[L - 1], s1 = (int)lvlend[L];
+        for (int base = s0; base < s1; base += kWave) {
+            const int i = base + lane;
+            if (i < s1) {
+                const uint32_t step = sorted[i];
+                const int row = (int)(step & 0xFFFFu);
+                const uint32_t tgt = step >> 16;
+                uint32_t sum = 0, lce = 0;
+#pragma unroll
+                for (int t = 0; t < MAXDEG; t++) {
+                    const uint32_t c = ell_col[t * mpad + row];
+                    if (c != 0xFFFFu) {
+                        const uint32_t lc = ell_logc[t * mpad + row];
+                        if (c == tgt) lce = lc;
+                        else {
+                            const uint32_t v = y[c];
+                            if (v) sum ^= ex[lg[v] + lc];
+                        }
+                    }
+                }
+                y[tgt] = sum ? ex[lg[sum] + 255u - lce] : (uint8_t)0;
+            }
+            wave_sync();
+        }
+    }
+
+    // ---- write Msg (...Decoder.m:129); unknown symbols are 0
+    uint8_t *o = a.out + f * n;
+    if ((n & 3) == 0) {
+        const uint32_t *yw = reinterpret_cast<const uint32_t *>(y);
+        uint32_t *ow = reinterpret_cast<uint32_t *>(o);
+        for (int i = lane; i < (n >> 2); i += kWave) ow[i] = yw[i];
+    } else {
+        for (int j = lane; j < n; j += kWave) o[j] = y[j];
+    }
+}
+
+// =================================================================================================
+// Kernel B (packets, S a multiple of 16): copy the received rows and execute the frame's steps.
+// One workgroup per frame; one wavefront executes one step at a time:
+//     out[e] = inv(h_ie) * XOR_{j != e} h_ij * out[j]           16 bytes per lane, coefficient wave-uniform
+// =================================================================================================
+struct ApplyArgs {
+    DevCode code;
+    int S;
+    int64_t nframes;
+    const uint8_t *sym;      // [nframes][in_rows][S]
+    const uint8_t *erased;   // [nframes][n] or nullptr (encode)
+    int in_rows;
+    uint8_t *out;            // [nframes][n][S]
+    const uint32_t *sched_hdr;     // per frame, or nullptr for the static encode schedule
+    const uint32_t *sched_steps;
+    const uint16_t *sched_lvlend;
+};
+
+__global__ __launch_bounds__(512) void ldpc_apply_kernel(ApplyArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const DevCode &cd = a.code;
+    const int n = cd.n, m = cd.m, S = a.S;
+    const int64_t f = blockIdx.x;
+    const int lane = lane_id(), wave = wave_id();
+    const int nw = (int)(blockDim.x >> 6);
+
+    uint32_t *steps = reinterpret_cast<uint32_t *>(smem);
+    uint16_t *lvlend = reinterpret_cast<uint16_t *>(smem + (size_t)m * 4);
+    int nsteps, nlev;
+    if (a.sched_hdr) {
+        nsteps = (int)a.sched_hdr[2 * f];
+        nlev = (int)a.sched_hdr[2 * f + 1];
+        const uint32_t *gs = a.sched_steps + f * m;
+        const uint16_t *gl = a.sched_lvlend + f * (m + 1);
+        for (int i = (int)threadIdx.x; i < nsteps; i += (int)blockDim.x) steps[i] = gs[i];
+        for (int i = (int)threadIdx.x; i <= nlev; i += (int)blockDim.x) lvlend[i] = gl[i];
+    } else {
+        nsteps = m;
+        nlev = cd.enc_nlevels;
+        for (int i = (int)threadIdx.x; i < nsteps; i += (int)blockDim.x) steps[i] = cd.enc_steps[i];
+        for (int i = (int)threadIdx.x; i <= nlev; i += (int)blockDim.x) lvlend[i] = cd.enc_lvlend[i];
+    }
+
+    // ---- copy phase: received rows in -> out, erased rows zero-filled (unknown symbols read as 0)
+    const uint8_t *fin = a.sym + f * (int64_t)a.in_rows * S;
+    uint8_t *fout = a.out + f * (int64_t)n * S;
+    const uint8_t *er = a.erased ? a.erased + f * n : nullptr;
+    {
+        const int64_t units = (int64_t)n * S / 16;
+        const U4 zero = {0, 0, 0, 0};
+        for (int64_t u = threadIdx.x; u < units; u += blockDim.x) {
+            const int row = (int)((u * 16) / S);
+            const bool e = er ? (er[row] != 0) : (row >= a.in_rows);
+            U4 v = zero;
+            if (!e) v = *reinterpret_cast<const U4 *>(fin + u * 16);
+            *reinterpret_cast<U4 *>(fout + u * 16) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- steps, level by level
+    const int pieces = (S + 1023) / 1024;
+    for (int L = 1; L <= nlev; L++) {
+        const int s0 = lvlend[L - 1], s1 = lvlend[L];
+        for (int s = s0 + wave; s < s1; s += nw) {
+            const uint32_t step = uniform(steps[s]);
+            const uint32_t row = step & 0xFFFFu, tgt = step >> 16;
+            const uint32_t e0 = cd.row_ptr[row], e1 = cd.row_ptr[row + 1];
+            for (int p = 0; p < pieces; p++) {
+                const int off = p * 1024 + lane * 16;
+                const bool active = off < S;
+                U4 acc = {0, 0, 0, 0};
+                uint32_t ctgt = 1;
+                for (uint32_t e = e0; e < e1; e++) {
+                    const uint32_t ed = cd.edges[e];
+                    const uint32_t col = ed & 0xFFFFu, c = (ed >> 16) & 0xFFu;
+                    if (col == tgt) { ctgt = c; continue; }
+                    if (active) {
+                        const U4 v = *reinterpret_cast<const U4 *>(fout + (int64_t)col * S + off);
+                        gfmac16(acc, load_multab(c), v);
+                    }
+                }
+                if (active) {
+                    const U4 r = gfmul16(load_multab(uniform(c_inv[ctgt])), acc);
+                    *reinterpret_cast<U4 *>(fout + (int64_t)tgt * S + off) = r;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// =================================================================================================
+// Kernel C: ML stage (a2-a4) for the residual frames.  One workgroup per frame (grid-stride over the
+// compacted list).  Working set: the augmented matrix [ H(:,erased) | rhs ] , m rows of W bytes, in a
+// per-workgroup global scratch (L2 resident); pivot row and pivot column staged in LDS.
+//
+// Exactness: the reference picks as pivot the FIRST row >= col with a non-zero in column col (:86), swaps
+// it to row col (:92-97), scales it by the inverse of its leading entry (:99-105), eliminates only the rows
+// BELOW (:107-114), and on an empty column stops (:87-90) but still writes rhs(1:E) back (:127).  The same
+// sequence is executed here, so rank-deficient frames produce the reference's bytes too.
+// =================================================================================================
+struct MlArgs {
+    DevCode code;
+    int S;
+    int W;      // row stride in bytes = Wa + Spad
+    int Wa;     // bytes reserved for the matrix part (round16(m))
+    const int32_t *ml_list;
+    const uint8_t *ml_state;
+    uint8_t *out;           // [nframes][n][S]
+    uint8_t *ws;            // [gridDim.x][m][W]
+    int32_t *status;
+    // LDS offsets
+    int lds_colmap, lds_elist, lds_colv, lds_prow, lds_arow, lds_misc;
+};
+
+__global__ __launch_bounds__(256) void ldpc_ml_kernel(MlArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const DevCode &cd = a.code;
+    const int n = cd.n, m = cd.m, S = a.S, W = a.W, Wa = a.Wa;
+    const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
+    const int lane = lane_id(), wave = wave_id(), nw = nthr >> 6;
+    const int Spad = W - Wa;
+
+    uint16_t *colmap = reinterpret_cast<uint16_t *>(smem + a.lds_colmap);  // [n]
+    uint16_t *elist = reinterpret_cast<uint16_t *>(smem + a.lds_elist);    // [m]
+    uint8_t *colv = smem + a.lds_colv;                                       // [mpad]
+    U4 *prow = reinterpret_cast<U4 *>(smem + a.lds_prow);                   // [W/16]
+    uint8_t *arow = smem + a.lds_arow;                                       // [nw][Wa]
+    int *misc = reinterpret_cast<int *>(smem + a.lds_misc);                 // [0] pivot, [1] E
+
+    uint8_t *ws = a.ws + (size_t)blockIdx.x * m * W;
+    const int count = a.ml_list[0];
+
+    for (int slot = (int)blockIdx.x; slot < count; slot += (int)gridDim.x) {
+        const int64_t f = a.ml_list[1 + slot];
+        const uint8_t *state = a.ml_state + (int64_t)slot * n;
+        uint8_t *fout = a.out + f * (int64_t)n * S;
+        __syncthreads();
+
+        // ---- erasure_ind = find(y_current == -1), ascending (:63)
+        if (wave == 0) {
+            int E = 0;
+            for (int j0 = 0; j0 < n; j0 += kWave) {
+                const int j = j0 + lane;
+                const bool e = (j < n) && state[j];
+                const uint64_t mask = __ballot(e);
+                const int pos = E + __popcll(mask & ((1ull << lane) - 1ull));
+                if (j < n) colmap[j] = e ? (uint16_t)pos : (uint16_t)0xFFFFu;
+                if (e) elist[pos] = (uint16_t)j;
+                E += __popcll(mask);
+            }
+            if (lane == 0) misc[1] = E;
+        }
+        __syncthreads();
+        const int E = misc[1];
+        const int Ea = (E + 15) & ~15;
+        const int ach = Ea >> 4;          // chunks of the matrix part actually in use
+        const int rch0 = Wa >> 4;         // first rhs chunk
+        const int rch = Spad >> 4;        // rhs chunks
+
+        // ---- find_inv = H(:, erasure_ind) (:65) and rhs(kk) = sum over known neighbours (:74-82)
+        for (int r = wave; r < m; r += nw) {
+            uint8_t *ar = arow + (size_t)wave * Wa;
+            for (int i = lane; i < ach; i += kWave) reinterpret_cast<U4 *>(ar)[i] = U4{0, 0, 0, 0};
+            wave_sync();
+            const uint32_t e0 = cd.row_ptr[r], e1 = cd.row_ptr[r + 1];
+            uint8_t *wrow = ws + (size_t)r * W;
+            if (S == 1) {
+                uint32_t prod = 0;
+                if (e0 + lane < e1) {
+                    const uint32_t ed = cd.edges[e0 + lane];
+                    const uint32_t col = ed & 0xFFFFu, c = (ed >> 16) & 0xFFu;
+                    const uint32_t cm = colmap[col];
+                    if (cm != 0xFFFFu) ar[cm] = (uint8_t)c;
+                    else prod = gfmul_log(c_log, c_exp, c, fout[col]);
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) prod ^= __shfl_xor(prod, d);
+                if (lane == 0) *reinterpret_cast<U4 *>(wrow + Wa) = U4{prod, 0, 0, 0};
+            } else {
+                for (uint32_t e = e0 + lane; e < e1; e += kWave) {
+                    const uint32_t ed = cd.edges[e];
+                    const uint32_t cm = colmap[ed & 0xFFFFu];
+                    if (cm != 0xFFFFu) ar[cm] = (uint8_t)((ed >> 16) & 0xFFu);
+                }
+                for (int i = lane; i < rch; i += kWave) {
+                    U4 acc = {0, 0, 0, 0};
+                    for (uint32_t e = e0; e < e1; e++) {
+                        const uint32_t ed = cd.edges[e];
+                        const uint32_t col = ed & 0xFFFFu, c = (ed >> 16) & 0xFFu;
+                        if (colmap[col] != 0xFFFFu) continue;
+                        const U4 v = *reinterpret_cast<const U4 *>(fout + (int64_t)col * S + i * 16);
+                        gfmac16(acc, load_multab(c), v);
+                    }
+                    *reinterpret_cast<U4 *>(wrow + Wa + i * 16) = acc;
+                }
+            }
+            wave_sync();
+            for (int i = lane; i < ach; i += kWave)
+                reinterpret_cast<U4 *>(wrow)[i] = reinterpret_cast<const U4 *>(ar)[i];
+            wave_sync();
+        }
+        if (tid == 0) misc[0] = 0x7FFFFFFF;
+        __syncthreads();
+
+        // ---- forward elimination (:85-115)
+        int dont_do_jordan = 0;
+        for (int col = 0; col < E; col++) {
+            for (int r = col + tid; r < m; r += nthr) {   // :86 non_zero_ind = find(find_inv(col:end, col))
+                const uint8_t v = ws[(size_t)r * W + col];
+                colv[r] = v;
+                if (v) atomicMin(&misc[0], r);
+            }
+            __syncthreads();
+            const int p = misc[0];
+            if (p == 0x7FFFFFFF) { dont_do_jordan = 1; break; }   // :87-90
+            // swap rows col <-> p (:92-97), scale the pivot row by the inverse of its leading entry (:99-105)
+            {
+                const uint32_t pinv = c_inv[colv[p]];
+                const MulTab t = load_multab(pinv);
+                const int c0 = col >> 4;
+                uint8_t *rp = ws + (size_t)p * W, *rc = ws + (size_t)col * W;
+                for (int i = tid; i < (ach - c0) + rch; i += nthr) {
+                    const int ci = (i < ach - c0) ? (c0 + i) : (rch0 + (i - (ach - c0)));
+                    const U4 vp = *reinterpret_cast<const U4 *>(rp + ci * 16);
+                    const U4 sc = gfmul16(t, vp);
+                    if (p != col) {
+                        const U4 vc = *reinterpret_cast<const U4 *>(rc + ci * 16);
+                        *reinterpret_cast<U4 *>(rp + ci * 16) = vc;
+                    }
+                    *reinterpret_cast<U4 *>(rc + ci * 16) = sc;
+                    prow[ci] = sc;
+                }
+            }
+            __syncthreads();
+            // zero out the other non-zero rows below (:107-114); rows in (col, p] are zero in this column
+            for (int r = p + 1 + wave; r < m; r += nw) {
+                const uint32_t fct = colv[r];
+                if (fct == 0) continue;
+                const MulTab t = load_multab(uniform(fct));
+                const int c0 = col >> 4;
+                uint8_t *rr = ws + (size_t)r * W;
+                for (int i = lane; i < (ach - c0) + rch; i += kWave) {
+                    const int ci = (i < ach - c0) ? (c0 + i) : (rch0 + (i - (ach - c0)));
+                    U4 v = *reinterpret_cast<const U4 *>(rr + ci * 16);
+                    gfmac16(v, t, prow[ci]);
+                    *reinterpret_cast<U4 *>(rr + ci * 16) = v;
+                }
+            }
+            if (tid == 0) misc[0] = 0x7FFFFFFF;
+            __syncthreads();
+        }
+
+        // ---- Jordan elimination on the upper triangle, rhs only (:117-126)
+        if (!dont_do_jordan) {
+            for (int col = E - 1; col >= 1; col--) {
+                for (int r = tid; r < col; r += nthr) colv[r] = ws[(size_t)r * W + col];
+                for (int i = tid; i < rch; i += nthr)
+                    prow[rch0 + i] = *reinterpret_cast<const U4 *>(ws + (size_t)col * W + Wa + i * 16);
+                __syncthreads();
+                for (int r = wave; r < col; r += nw) {
+                    const uint32_t fct = colv[r];
+                    if (fct == 0) continue;
+                    const MulTab t = load_multab(uniform(fct));
+                    uint8_t *rr = ws + (size_t)r * W + Wa;
+                    for (int i = lane; i < rch; i += kWave) {
+                        U4 v = *reinterpret_cast<const U4 *>(rr + i * 16);
+                        gfmac16(v, t, prow[rch0 + i]);
+                        *reinterpret_cast<U4 *>(rr + i * 16) = v;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+
+        // ---- y_current(erasure_ind) = rhs(1:num_erasures) -- unconditional (:127)
+        if (S == 1) {
+            for (int t = tid; t < E; t += nthr) fout[elist[t]] = ws[(size_t)t * W + Wa];
+        } else {
+            for (int t = wave; t < E; t += nw) {
+                const uint8_t *src = ws + (size_t)t * W + Wa;
+                uint8_t *dst = fout + (int64_t)elist[t] * S;
+                for (int i = lane; i < rch; i += kWave)
+                    *reinterpret_cast<U4 *>(dst + i * 16) = *reinterpret_cast<const U4 *>(src + i * 16);
+            }
+        }
+        if (tid == 0 && a.status) a.status[f] = dont_do_jordan ? LDPC_AMD_ST_ML_RANKDEF : LDPC_AMD_ST_ML_SOLVED;
+        if (tid == 0) misc[0] = 0x7FFFFFFF;
+    }
+}
+
+// =================================================================================================
+// Synthetic inputs (role of the FPGA data_in kernel, OpenCL/device/ldpc_erasure_decoder_top.cl:57-120)
+// =================================================================================================
+__global__ void synth_bytes_kernel(uint64_t seed, uint32_t stream, uint64_t base, uint64_t count, uint8_t *dst)
+{
+    // 4 bytes per thread
+    const uint64_t words = (count + 3) / 4;
+    for (uint64_t w = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; w < words; w += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t v = 0;
+        for (int b = 0; b < 4; b++) {
+            const uint64_t i = w * 4 + b;
+            if (i < count) v |= (uint32_t)ldpc_synth_byte(seed, stream, base + i) << (8 * b);
+        }
+        if (w * 4 + 3 < count) reinterpret_cast<uint32_t *>(dst)[w] = v;
+        else for (int b = 0; b < 4 && w * 4 + b < count; b++) dst[w * 4 + b] = (uint8_t)(v >> (8 * b));
+    }
+}
+
+__global__ void synth_bernoulli_kernel(uint64_t seed, uint32_t stream, uint64_t base, uint64_t count,
+                                       uint64_t thresh, uint8_t *dst)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x)
+        dst[i] = (uint8_t)ldpc_synth_bernoulli(seed, stream, base + i, thresh);
+}
+
+// =================================================================================================
+// Self-test of the packed multiply against the log/antilog tables
+// =================================================================================================
+__global__ void selftest_kernel(int *bad)
+{
+    const uint32_t c = blockIdx.x;  // 0..255
+    const MulTab t = load_multab(c);
+    const uint32_t x = threadIdx.x; // 0..255
+    const uint32_t packed = x | ((x ^ 0x5Au) << 8) | ((255u - x) << 16) | (((x * 7u) & 0xFFu) << 24);
+    const uint32_t got = gfmul4(t, packed);
+    uint32_t want = 0;
+    for (int b = 0; b < 4; b++) {
+        const uint32_t xb = (packed >> (8 * b)) & 0xFFu;
+        want |= gfmul_log(c_log, c_exp, c, xb) << (8 * b);
+    }
+    if (got != want) atomicAdd(bad, 1);
+    if (x == 0 && c != 0) {
+        if (gfmul_log(c_log, c_exp, c, c_inv[c]) != 1u) atomicAdd(bad, 1);
+    }
+}
+
+#include "rs_kernels.inc"
+#include "fpga_kernels.inc"
+
+}  // namespace
+
+// =================================================================================================
+// Host side: constants, LDS layouts, launches
+// =================================================================================================
+hipError_t upload_constants(hipStream_t s)
+{
+    static uint32_t tab[256 * 8];
+    build_mul3_tables(tab);
+    const GfHost &g = gf_host();
+    hipError_t e;
+    if ((e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_mul3), tab, sizeof(tab), 0, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+    if ((e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_log), g.log, 256, 0, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+    if ((e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_exp), g.exp, 512, 0, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+    if ((e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_inv), g.inv, 256, 0, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+    return hipStreamSynchronize(s);
+}
+
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+static PeelLds make_peel_lds(const DevCode &cd, bool fused, int wpb)
+{
+    PeelLds L{};
+    int off = 0;
+    L.ell_col = off; off += align_up(cd.degpad * cd.mpad * 2, 16);
+    L.ell_logc = off; if (fused) off += align_up(cd.degpad * cd.mpad, 16);
+    L.lg = off; if (fused) off += 256;
+    L.ex = off; if (fused) off += 512;
+    L.wave0 = off;
+    int w = 0;
+    L.st = w; w += align_up(std::max(2 * cd.n, 4 * (cd.m + 2)), 16);
+    L.y = w; if (fused) w += align_up(cd.n, 16);
+    L.steps = w; w += align_up(4 * cd.m, 16);
+    L.slvl = w; w += align_up(2 * cd.m, 16);
+    L.sorted = w; w += align_up(4 * cd.m, 16);
+    L.wave_stride = w;
+    L.total = off + wpb * w;
+    return L;
+}
+
+template <bool FUSED>
+static hipError_t launch_peel_t(const PeelArgs &a, int wpb, hipStream_t s)
+{
+    const int grid = (int)((a.nframes + wpb - 1) / wpb);
+    const dim3 g(grid), b(wpb * 64);
+    const size_t lds = (size_t)a.lds.total;
+#define LDPC_PEEL_CASE(D)                                                                                  \
+    case D: {                                                                                              \
+        auto kfn = ldpc_peel_kernel<D, FUSED>;                                                             \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                           \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+        if (e != hipSuccess) return e;                                                                     \
+        hipLaunchKernelGGL(kfn, g, b, lds, s, a);                                                          \
+        return hipGetLastError();                                                                          \
+    }
+    switch (a.code.degpad) {
+        LDPC_PEEL_CASE(8)
+        LDPC_PEEL_CASE(16)
+        LDPC_PEEL_CASE(24)
+    }
+#undef LDPC_PEEL_CASE
+    return hipErrorInvalidValue;
+}
+
+static const int kLdsMax = 160 * 1024;
+
+int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
+{
+    const DevCode &cd = d.code;
+    if (d.nframes <= 0) return LDPC_AMD_OK;
+    const bool fused = (d.S == 1) && !d.flags_only;
+    if (!fused && !d.flags_only && (d.S % 16) != 0) return set_error(ctx, LDPC_AMD_EUNSUP, "S must be 1 or a multiple of 16 (got %d)", d.S);
+    if (d.max_sweeps < 1) return set_error(ctx, LDPC_AMD_EINVAL, "max_sweeps must be >= 1");
+
+    // workgroup shape: as many frames per workgroup as fit comfortably in LDS
+    int wpb = 4;
+    PeelLds L = make_peel_lds(cd, fused, wpb);
+    while (wpb > 1 && L.total > 80 * 1024) { wpb >>= 1; L = make_peel_lds(cd, fused, wpb); }
+    if (L.total > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "code too large for LDS (%d bytes)", L.total);
+
+    const int64_t nf = d.nframes;
+    int rc;
+    if ((rc = scratch_reserve(ctx, ctx->mllist, sizeof(int32_t) * (size_t)(nf + 1)))) return rc;
+    if (d.do_ml && (rc = scratch_reserve(ctx, ctx->mlstate, (size_t)nf * cd.n))) return rc;
+    LDPC_HIP_TRY(ctx, hipMemsetAsync(ctx->mllist.p, 0, sizeof(int32_t), ctx->stream));
+
+    PeelArgs pa{};
+    pa.code = cd; pa.lds = L; pa.nframes = nf; pa.sym = d.sym; pa.erased = d.erased; pa.in_rows = d.in_rows;
+    pa.max_sweeps = d.max_sweeps; pa.do_ml = d.do_ml; pa.out = d.out;
+    pa.sweeps = d.sweeps; pa.residual = d.residual; pa.status = d.status; pa.residual_sys = d.residual_sys;
+    pa.ml_list = (int32_t *)ctx->mllist.p; pa.ml_state = (uint8_t *)ctx->mlstate.p;
+
+    if (d.flags_only) {
+        LDPC_HIP_TRY(ctx, launch_peel_t<false>(pa, wpb, ctx->stream));
+        return LDPC_AMD_OK;
+    }
+    if (fused) {
+        hipEvent_t ev = prof_begin(ctx);
+        LDPC_HIP_TRY(ctx, launch_peel_t<true>(pa, wpb, ctx->stream));
+        prof_end(ctx, LDPC_AMD_PROF_PEEL, ev);
+    } else {
+        const size_t hdr = (size_t)nf * 2 * 4, st = (size_t)nf * cd.m * 4, le = (size_t)nf * (cd.m + 1) * 2;
+        const size_t o1 = (hdr + 255) & ~(size_t)255, o2 = (o1 + st + 255) & ~(size_t)255;
+        if ((rc = scratch_reserve(ctx, ctx->sched, o2 + le))) return rc;
+        unsigned char *base = (unsigned char *)ctx->sched.p;
+        pa.sched_hdr = (uint32_t *)base; pa.sched_steps = (uint32_t *)(base + o1); pa.sched_lvlend = (uint16_t *)(base + o2);
+        hipEvent_t ev = prof_begin(ctx);
+        LDPC_HIP_TRY(ctx, launch_peel_t<false>(pa, wpb, ctx->stream));
+        prof_end(ctx, LDPC_AMD_PROF_PEEL, ev);
+
+        ApplyArgs aa{};
+        aa.code = cd; aa.S = d.S; aa.nframes = nf; aa.sym = d.sym; aa.erased = d.erased; aa.in_rows = d.in_rows; aa.out = d.out;
+        aa.sched_hdr = pa.sched_hdr; aa.sched_steps = pa.sched_steps; aa.sched_lvlend = pa.sched_lvlend;
+        const size_t lds = (size_t)cd.m * 4 + (size_t)(cd.m + 2) * 2;
+        ev = prof_begin(ctx);
+        hipLaunchKernelGGL(ldpc_apply_kernel, dim3((unsigned)nf), dim3(512), lds, ctx->stream, aa);
+        LDPC_HIP_TRY(ctx, hipGetLastError());
+        prof_end(ctx, LDPC_AMD_PROF_APPLY, ev);
+    }
+
+    if (d.do_ml) {
+        MlArgs ma{};
+        ma.code = cd; ma.S = d.S;
+        ma.Wa = align_up(cd.m, 16);
+        const int Spad = fused ? 16 : d.S;
+        ma.W = ma.Wa + Spad;
+        ma.ml_list = (const int32_t *)ctx->mllist.p; ma.ml_state = (const uint8_t *)ctx->mlstate.p;
+        ma.out = d.out; ma.status = d.status;
+        const int nwv = 4;
+        int off = 0;
+        ma.lds_colmap = off; off += align_up(2 * cd.n, 16);
+        ma.lds_elist = off; off += align_up(2 * cd.m, 16);
+        ma.lds_colv = off; off += align_up(cd.mpad, 16);
+        ma.lds_prow = off; off += ma.W;
+        ma.lds_arow = off; off += nwv * ma.Wa;
+        ma.lds_misc = off; off += 16;
+        if (off > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "ML stage: LDS need %d bytes", off);
+        int grid = (int)std::min<int64_t>(nf, 2 * (int64_t)ctx->sm_count);
+        const size_t per = (size_t)cd.m * ma.W;
+        while (grid > 1 && per * grid > ((size_t)8 << 30)) grid >>= 1;
+        if ((rc = scratch_reserve(ctx, ctx->mlws, per * grid))) return rc;
+        ma.ws = (uint8_t *)ctx->mlws.p;
+        auto kfn = ldpc_ml_kernel;
+        LDPC_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, off));
+        hipEvent_t ev = prof_begin(ctx);
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(nwv * 64), (size_t)off, ctx->stream, ma);
+        LDPC_HIP_TRY(ctx, hipGetLastError());
+        prof_end(ctx, LDPC_AMD_PROF_ML, ev);
+    }
+    return LDPC_AMD_OK;
+}
+
+int launch_encode(ldpc_amd_ctx *ctx, const DevCode &cd, int S, int64_t nframes, const uint8_t *src, uint8_t *cw)
+{
+    if (nframes <= 0) return LDPC_AMD_OK;
+    if (S == 1) {
+        // all parity symbols erased: one in-order sweep of the peeling decoder IS the encoder
+        // (row i has exactly one unknown, column k+i, once rows < i are done: triangle form).
+        DecodeArgs d{};
+        d.code = cd; d.S = 1; d.nframes = nframes; d.sym = src; d.erased = nullptr; d.in_rows = cd.k;
+        d.max_sweeps = 1; d.do_ml = 0; d.out = cw;
+        return launch_decode(ctx, d);
+    }
+    if (S % 16) return set_error(ctx, LDPC_AMD_EUNSUP, "S must be 1 or a multiple of 16 (got %d)", S);
+    ApplyArgs aa{};
+    aa.code = cd; aa.S = S; aa.nframes = nframes; aa.sym = src; aa.erased = nullptr; aa.in_rows = cd.k; aa.out = cw;
+    const size_t lds = (size_t)cd.m * 4 + (size_t)(cd.m + 2) * 2;
+    hipLaunchKernelGGL(ldpc_apply_kernel, dim3((unsigned)nframes), dim3(512), lds, ctx->stream, aa);
+    LDPC_HIP_TRY(ctx, hipGetLastError());
+    return LDPC_AMD_OK;
+}
+
+int launch_rs_decode(ldpc_amd_ctx *ctx, const HostRs &rs, int S, int64_t nblocks, const uint16_t *idx,
+                     const uint8_t *val, uint8_t *msg)
+{
+    if (nblocks <= 0) return LDPC_AMD_OK;
+    const int R = rs.n - rs.k;
+    RsArgs a{};
+    a.n = rs.n; a.k = rs.k; a.S = S; a.nblocks = nblocks; a.pt = rs.d_pt; a.recv_idx = idx; a.recv_val = val; a.msg = msg;
+    int off = 0;
+    a.lds_idx = off; off += align_up(2 * rs.k, 16);
+    a.lds_pres = off; off += align_up(rs.k, 16);
+    a.lds_ulist = off; off += align_up(rs.k, 16);
+    a.lds_M = off; off += align_up(2 * R * R, 16);
+    a.lds_b = off; off += align_up(R, 16);
+    a.lds_lg = off; off += 256;
+    a.lds_ex = off; off += 512;
+    a.lds_misc = off; off += 16;
+    if (off > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "RS decode: LDS need %d bytes", off);
+    const int threads = (S == 1) ? 64 : 256;
+    int grid = (int)std::min<int64_t>(nblocks, (int64_t)ctx->sm_count * (S == 1 ? 16 : 4));
+    if (S != 1) {
+        int rc = scratch_reserve(ctx, ctx->rsws, (size_t)grid * R * S);
+        if (rc) return rc;
+        a.ws = (uint8_t *)ctx->rsws.p;
+    }
+    auto kfn = rs_decode_kernel;
+    LDPC_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, off));
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(threads), (size_t)off, ctx->stream, a);
+    LDPC_HIP_TRY(ctx, hipGetLastError());
+    return LDPC_AMD_OK;
+}
+
+int launch_rs_encode(ldpc_amd_ctx *ctx, const HostRs &rs, int S, int64_t nblocks, const uint8_t *src, uint8_t *cw)
+{
+    if (nblocks <= 0) return LDPC_AMD_OK;
+    const int grid = (int)std::min<int64_t>(nblocks, (int64_t)ctx->sm_count * 8);
+    hipLaunchKernelGGL(rs_encode_kernel, dim3(grid), dim3(256), 0, ctx->stream, rs.n, rs.k, S, nblocks,
+                       (const uint8_t *)rs.d_pt, src, cw);
+    LDPC_HIP_TRY(ctx, hipGetLastError());
+    return LDPC_AMD_OK;
+}
+
+int launch_fpga_stats(ldpc_amd_ctx *ctx, const DevCode &code, int rs_n, int rs_k, int64_t nframes,
+                      const uint8_t *erased0, const int32_t *residual_sys, int32_t *stats)
+{
+    LDPC_HIP_TRY(ctx, hipMemsetAsync(stats, 0, 2 * sizeof(int32_t), ctx->stream));
+    const int grid = (int)std::min<int64_t>((nframes + 3) / 4, 4096);
+    hipLaunchKernelGGL(fpga_stats_kernel, dim3(grid), dim3(256), 0, ctx->stream, code.n, rs_n, rs_k, nframes, erased0,
+                       residual_sys, stats);
+    LDPC_HIP_TRY(ctx, hipGetLastError());
+    return LDPC_AMD_OK;
+}
+
+int launch_selftest(ldpc_amd_ctx *ctx)
+{
+    int rc;
+    if ((rc = scratch_reserve(ctx, ctx->stage_i32, 64))) return rc;
+    int *d = (int *)ctx->stage_i32.p;
+    LDPC_HIP_TRY(ctx, hipMemsetAsync(d, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(selftest_kernel, dim3(256), dim3(256), 0, ctx->stream, d);
+    LDPC_HIP_TRY(ctx, hipGetLastError());
+    int bad = -1;
+    LDPC_HIP_TRY(ctx, hipMemcpyAsync(&bad, d, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (bad != 0) return set_error(ctx, LDPC_AMD_EHIP, "GF(256) self-test: %d mismatches", bad);
+    return LDPC_AMD_OK;
+}
+
+int launch_synth_source(ldpc_amd_ctx *ctx, uint64_t seed, int64_t frame0, int64_t nframes, int k, int S, uint8_t *d)
+{
+    const uint64_t base = (uint64_t)frame0 * (uint64_t)k * (uint64_t)S;
+    const uint64_t count = (uint64_t)nframes * (uint64_t)k * (uint64_t)S;
+    if (count == 0) return LDPC_AMD_OK;
+    const uint64_t words = (count + 3) / 4;
+    const int grid = (int)std::min<uint64_t>((words + 255) / 256, 16384);
+    hipLaunchKernelGGL(synth_bytes_kernel, dim3(grid), dim3(256), 0, ctx->stream, seed, (uint32_t)LDPC_SYNTH_STREAM_SOURCE, base, count, d);
+    LDPC_HIP_TRY(ctx, hipGetLastError());
+    return LDPC_AMD_OK;
+}
+
+int launch_synth_erasures(ldpc_amd_ctx *ctx, uint64_t seed, uint32_t stream_id, int64_t first, int64_t count,
+                          uint64_t thresh, uint8_t *d)
+{
+    if (count <= 0) return LDPC_AMD_OK;
+    const int grid = (int)std::min<int64_t>((count + 255) / 256, 16384);
+    hipLaunchKernelGGL(synth_bernoulli_kernel, dim3(grid), dim3(256), 0, ctx->stream, seed, stream_id, (uint64_t)first,
+                       (uint64_t)count, thresh, d);
+    LDPC_HIP_TRY(ctx, hipGetLastError());
+    return LDPC_AMD_OK;
+}
+
+}  // namespace ldpc_amd

@@ -135,6 +135,26 @@ void oracle_ldpc_encode(const oracle_code *c, const uint8_t *source, uint8_t *co
     }
 }
 
+void oracle_ldpc_encode_packets(const oracle_code *c, int S, const uint8_t *source, uint8_t *codeword)
+{
+    const oracle_gf *gf = oracle_gf_default();
+    memset(codeword, 0, (size_t)c->n * S);      /* :174 */
+    memcpy(codeword, source, (size_t)c->k * S); /* :175 */
+    uint8_t *gf_sum = (uint8_t *)malloc((size_t)S);
+    for (int pp = 0; pp < c->m; pp++) {         /* :176 */
+        memset(gf_sum, 0, (size_t)S);           /* :177 */
+        for (int ll = 1; ll <= VV(pp, 0) - 1; ll++) { /* :178-179 */
+            const uint8_t *row = gf->mult[VV(pp, ll)];
+            const uint8_t *src = &codeword[(size_t)(VL(pp, ll) - 1) * S];
+            for (int l = 0; l < S; l++) gf_sum[l] = GF_ADD(gf_sum[l], row[src[l]]);
+        }
+        const uint8_t *irow = gf->mult[GF_INV(VV(pp, VV(pp, 0)))]; /* :181 */
+        uint8_t *dst = &codeword[(size_t)(c->k + pp) * S];
+        for (int l = 0; l < S; l++) dst[l] = irow[gf_sum[l]];
+    }
+    free(gf_sum);
+}
+
 /* ============================ hybrid MP + ML decoder, lane-vectorised ============================ */
 /* Matlab/My_LDPC_HybridML_NonBinary_Erasure_Decoder.m.  y[n*S] with flag era[n] standing for the
  * value -1; S = 1 is the reference exactly, S > 1 runs the same statements on S independent byte

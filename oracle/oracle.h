@@ -57,6 +57,8 @@ void oracle_code_destroy(oracle_code *c);
 /* ---- a8: systematic encoder, Matlab/ErasureCodes_NonBinaryLDPCSim.m:174-182 -------------------- */
 /* source[k] -> codeword[n] (codeword[0..k) = source). */
 void oracle_ldpc_encode(const oracle_code *c, const uint8_t *source, uint8_t *codeword);
+/* Same statements on S independent byte lanes: source[k*S] -> codeword[n*S]. */
+void oracle_ldpc_encode_packets(const oracle_code *c, int S, const uint8_t *source, uint8_t *codeword);
 
 /* ---- a1-a4: Matlab/My_LDPC_HybridML_NonBinary_Erasure_Decoder.m:4-130 --------------------------
  * recv[n]: 0..255 or -1 (erasure, ...Decoder.m:9).  itenum: sweep cap (reference constant 10, :13).

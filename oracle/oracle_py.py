@@ -43,6 +43,7 @@ def lib():
     L.oracle_code_create.argtypes = [C.c_int, C.c_int, u32p, u16p, u8p]
     L.oracle_code_destroy.argtypes = [C.c_void_p]
     L.oracle_ldpc_encode.argtypes = [C.c_void_p, u8p, u8p]
+    L.oracle_ldpc_encode_packets.argtypes = [C.c_void_p, C.c_int, u8p, u8p]
     L.oracle_ldpc_hybridml_nonbinary_decode.argtypes = [C.c_void_p, i16p, C.c_int, C.c_int, i16p,
                                                         C.POINTER(C.c_int), i32p]
     L.oracle_ldpc_hybridml_nonbinary_decode_packets.argtypes = [C.c_void_p, C.c_int, u8p, u8p, C.c_int, C.c_int,
@@ -106,10 +107,7 @@ class OracleCode:
         # [k, S] packets: encode every lane
         k, S = source.shape
         cw = np.zeros((self.n, S), dtype=np.uint8)
-        for l in range(S):
-            col = np.zeros(self.n, dtype=np.uint8)
-            lib().oracle_ldpc_encode(self._h, np.ascontiguousarray(source[:, l]), col)
-            cw[:, l] = col
+        lib().oracle_ldpc_encode_packets(self._h, S, source, cw)
         return cw
 
     def decode(self, recv, itenum=10, do_ml=1):
