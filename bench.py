@@ -207,9 +207,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cores = max(1, min(len(os.sched_getaffinity(0)), 16))
         # ~3 ms/frame/core at S=1024 and ~0.2 ms at S=1 on a current x86 core -> about 10 s of CPU work per core
-        cpu[args.S] = cpu_baseline(args.S, cores, args.cpu_frames or (64 if args.S > 1 else 8192))
+        cpu[args.S] = cpu_baseline(args.S, cores, args.cpu_frames or (1024 if args.S > 1 else 65536))
         if args.S != 1:
-            cpu[1] = cpu_baseline(1, cores, args.cpu_frames or 8192)
+            cpu[1] = cpu_baseline(1, cores, args.cpu_frames or 65536)
 
     result, n, k = run_gpu(args, rank, world, local_rank)
     if rank != 0:

@@ -56,6 +56,13 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise LdpcAmdError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(there is no CPU fallback)")
+    # PyTorch-ROCm ships its own libamdhip64.so.7 / libhsa-runtime64; two HIP runtimes in one process do not
+    # both see the GPU.  Loading torch first makes our library bind to the runtime torch uses (same SONAME),
+    # so device pointers, streams and events are shared between the two.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is optional plumbing: without it the system ROCm runtime is used
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64
     L.ldpc_amd_init.argtypes = [i32, C.POINTER(vp)]
