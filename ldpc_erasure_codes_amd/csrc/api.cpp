@@ -242,8 +242,14 @@ static int register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_pt
         }
     }
 
+    int maxcoldeg = 0;
+    {
+        std::vector<int> cdeg(n, 0);
+        for (int e = 0; e < hc->nnz; e++) maxcoldeg = std::max(maxcoldeg, ++cdeg[cols[e]]);
+    }
     DevCode &d = hc->dev;
     d.n = n; d.k = k; d.m = m; d.nnz = hc->nnz; d.maxdeg = maxdeg; d.degpad = degpad; d.mpad = mpad;
+    d.maxcoldeg = maxcoldeg;
     d.enc_nlevels = enc_nlevels;
     int rc;
     if ((rc = upload(ctx, hc, hc->row_ptr, &d.row_ptr)) || (rc = upload(ctx, hc, edges, &d.edges)) ||

@@ -37,6 +37,7 @@ void build_mul3_tables(uint32_t *tab /* [256*8] */);
 struct DevCode {
     int n, k, m, nnz;
     int maxdeg;   // largest row degree
+    int maxcoldeg;  // largest column degree (width of the per-frame padded source->target edge lists)
     int degpad;   // template bucket the kernels are instantiated for (8, 16 or 24) >= maxdeg
     int mpad;     // m rounded up to a multiple of 64
     const uint32_t *row_ptr;  // [m+1]

@@ -23,6 +23,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
 
 #include "internal.h"
 #include "gf256_dev.h"
@@ -157,6 +161,7 @@ struct PeelLds {        // byte offsets into dynamic LDS
     int steps;          // u32 [m]
     int slvl;           // u16 [m]
     int sorted;         // u32 [m]
+    int cnt;            // u32 [n]  per-source edge counters       (packet path only)
     int total;
 };
 
@@ -175,6 +180,9 @@ struct PeelArgs {
     uint32_t *sched_hdr;    // [nframes][2]  nsteps, maxlvl
     uint32_t *sched_steps;  // [nframes][m]
     uint16_t *sched_lvlend; // [nframes][m+1]
+    // packet path, scatter form: for every source symbol j the (slot, coefficient) pairs of the steps it feeds
+    uint8_t *src_cnt;       // [nframes][n]              number of pairs of symbol j  (or nullptr)
+    uint32_t *src_pad;      // [nframes][n][maxcoldeg]   slot | coef << 16, first src_cnt entries valid
     // ML hand-off
     int32_t *ml_list;       // [0] = count, [1..] frame ids
     uint8_t *ml_state;      // [slot][n]  1 = still erased
@@ -285,6 +293,32 @@ __global__ __launch_bounds__(256) void ldpc_peel_kernel(PeelArgs a)
         for (int i = lane; i < nsteps; i += kWave) gs[i] = sorted[i];
         uint16_t *gl = a.sched_lvlend + f * (m + 1);
         for (int i = lane; i <= maxlvl; i += kWave) gl[i] = (uint16_t)lvlend[i];
+        if (!a.src_cnt) return;
+        // Transpose the used checks: symbol j -> list of (slot of the step it feeds, H(row, j)).  The slot is
+        // the step's position in level order.  Every neighbour of a used check except its target is a source.
+        uint32_t *cnt = reinterpret_cast<uint32_t *>(wbase + a.lds.cnt);
+        for (int j = lane; j < n; j += kWave) cnt[j] = 0;
+        wave_sync();
+        const int cdw = cd.maxcoldeg;
+        uint32_t *gp = a.src_pad + f * (int64_t)n * cdw;
+        for (int s = lane; s < nsteps; s += kWave) {
+            const uint32_t step = sorted[s];
+            const int row = (int)(step & 0xFFFFu);
+            const uint32_t tgt = step >> 16;
+            const uint32_t e0 = cd.row_ptr[row];
+#pragma unroll
+            for (int t = 0; t < MAXDEG; t++) {
+                const uint32_t c = ell_col[t * mpad + row];
+                if (c != 0xFFFFu && c != tgt) {
+                    const uint32_t coef = (cd.edges[e0 + t] >> 16) & 0xFFu;
+                    const uint32_t pos = atomicAdd(&cnt[c], 1u);
+                    gp[(int64_t)c * cdw + pos] = (uint32_t)s | (coef << 16);
+                }
+            }
+        }
+        wave_sync();
+        uint8_t *gc = a.src_cnt + f * (int64_t)n;
+        for (int j = lane; j < n; j += kWave) gc[j] = (uint8_t)cnt[j];
         return;
     }
 
@@ -416,6 +450,191 @@ __global__ __launch_bounds__(512) void ldpc_apply_kernel(ApplyArgs a)
                     *reinterpret_cast<U4 *>(fout + (int64_t)tgt * S + off) = r;
                 }
             }
+        }
+        __syncthreads();
+    }
+}
+
+// =================================================================================================
+// Kernel B' (packets, the HBM-bound kernel): scatter form of the same arithmetic.
+//
+// Kernel B gathers: every step re-reads its ~12 source rows, so a row is fetched ~2.2 times (once for the
+// copy, ~1.3 times as a source) and the fetches are too far apart in time to hit in L2 / Infinity Cache.
+// Here every received row is read from HBM exactly ONCE: it is written to `out` and, while still in
+// registers, multiplied into the accumulators of the steps it feeds (the per-frame transposed lists the peel
+// kernel emits).  The accumulators of all steps of the frame slice live in LDS (T x B bytes, B = 16*LPR
+// bytes of every row per workgroup; 4 slices x 256 B for S = 1024 on the (2040,1530) code = 130 KB), updated
+// with ds_xor_b64.  HBM traffic per frame: 0.9 nS read + nS write -- the algorithmic minimum for an
+// out-of-place decode.  Solved symbols are finalised level by level (acc * inv(h)), written out and scattered
+// on to the later steps that use them.
+//
+// Coefficients differ between the 64/LPR row pieces a wavefront handles at once, so the multiply tables come
+// from an 8 KB LDS copy (two ds_reads per edge) instead of scalar registers.
+// =================================================================================================
+struct ScatterArgs {
+    DevCode code;
+    int S, nslices;
+    int64_t nframes;
+    const uint8_t *sym;
+    const uint8_t *erased;
+    uint8_t *out;
+    const uint32_t *sched_hdr;
+    const uint32_t *sched_steps;
+    const uint16_t *sched_lvlend;
+    const uint8_t *src_cnt;
+    const uint32_t *src_pad;
+    int lds_acc, lds_tgt, lds_invc, lds_lvlend, lds_solved, lds_mt;
+};
+
+__device__ __forceinline__ MulTab lds_multab(const uint32_t *mt, uint32_t c)
+{
+    const U4 q = *reinterpret_cast<const U4 *>(mt + c * 8);
+    MulTab t;
+    t.t0 = q.x; t.t1 = q.y; t.t2 = q.z; t.t3 = q.w; t.t4 = mt[c * 8 + 4];
+    return t;
+}
+
+// acc(16 bytes at p) ^= v, as two ds_xor_b64.  Lanes 8..15 of every 16-lane group issue their halves in the
+// opposite order, so that one instruction touches all 32 LDS banks exactly once per 16 lanes.
+__device__ __forceinline__ void lds_xor16(unsigned char *p, const U4 &v, int h)
+{
+    const unsigned long long lo = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
+    const unsigned long long hi = (unsigned long long)v.z | ((unsigned long long)v.w << 32);
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
+    __hip_atomic_fetch_xor(q + h, h ? hi : lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_xor(q + (1 - h), h ? lo : hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int LPR>
+__global__ __launch_bounds__(1024) void ldpc_scatter_kernel(ScatterArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RPW = 64 / LPR;              // row pieces per wave instruction
+    constexpr int KQ = (16 + LPR - 1) / LPR;   // edge words held per lane (maxcoldeg <= 16)
+    constexpr int R = (LPR >= 8) ? 4 : 1;      // row pieces in flight per lane
+    constexpr int B = 16 * LPR;                // bytes of every row handled by this workgroup
+    const DevCode &cd = a.code;
+    const int n = cd.n, S = a.S, cdw = cd.maxcoldeg;
+    const int64_t f = blockIdx.x / a.nslices;
+    const int sl = (int)(blockIdx.x % a.nslices);
+    const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
+    const int lane = lane_id(), wave = wave_id(), nw = nthr >> 6;
+    const int g = lane / LPR, gl = lane % LPR, h = (lane >> 3) & 1;
+    const int gbase = lane & ~(LPR - 1);
+
+    unsigned char *acc = smem + a.lds_acc;
+    uint16_t *tgt = reinterpret_cast<uint16_t *>(smem + a.lds_tgt);
+    uint8_t *invc = smem + a.lds_invc;
+    uint16_t *lvlend = reinterpret_cast<uint16_t *>(smem + a.lds_lvlend);
+    uint32_t *solved = reinterpret_cast<uint32_t *>(smem + a.lds_solved);
+    uint32_t *mt = reinterpret_cast<uint32_t *>(smem + a.lds_mt);
+
+    const int nsteps = (int)a.sched_hdr[2 * f], nlev = (int)a.sched_hdr[2 * f + 1];
+    const uint32_t *gs = a.sched_steps + f * cd.m;
+    const uint16_t *gle = a.sched_lvlend + f * (cd.m + 1);
+    for (int i = tid; i < (n + 31) / 32; i += nthr) solved[i] = 0;
+    for (int i = tid; i < 2048; i += nthr) mt[i] = c_mul3[i];
+    for (int i = tid; i <= nlev; i += nthr) lvlend[i] = gle[i];
+    for (int i = tid; i < nsteps * LPR; i += nthr) reinterpret_cast<U4 *>(acc)[i] = U4{0, 0, 0, 0};
+    __syncthreads();
+    for (int s = tid; s < nsteps; s += nthr) {
+        const uint32_t step = gs[s];
+        const uint32_t row = step & 0xFFFFu, t = step >> 16;
+        tgt[s] = (uint16_t)t;
+        uint32_t ct = 1;
+        for (uint32_t e = cd.row_ptr[row]; e < cd.row_ptr[row + 1]; e++) {
+            const uint32_t ed = cd.edges[e];
+            if ((ed & 0xFFFFu) == t) ct = (ed >> 16) & 0xFFu;
+        }
+        invc[s] = c_inv[ct];
+        atomicOr(&solved[t >> 5], 1u << (t & 31));
+    }
+    __syncthreads();
+
+    const uint8_t *fin = a.sym + f * (int64_t)n * S + (int64_t)sl * B + gl * 16;
+    uint8_t *fout = a.out + f * (int64_t)n * S + (int64_t)sl * B + gl * 16;
+    const uint8_t *er = a.erased + f * (int64_t)n;
+    const uint8_t *scnt = a.src_cnt + f * (int64_t)n;
+    const uint32_t *spad = a.src_pad + f * (int64_t)n * cdw;
+
+    // multiplies v into the accumulators of the steps that symbol j feeds (cn pairs, KQ words per lane)
+    auto scatter = [&](const U4 &v, int cn, const uint32_t (&ew)[KQ]) {
+#pragma unroll
+        for (int q = 0; q < KQ; q++) {
+            if (!__any(q * LPR < cn)) break;
+            for (int u = 0; u < LPR; u++) {
+                const int t = q * LPR + u;
+                if (!__any(t < cn)) break;
+                const uint32_t ed = (uint32_t)__shfl((int)ew[q], gbase + u);
+                if (t < cn) {
+                    const uint32_t s = ed & 0xFFFFu, c = (ed >> 16) & 0xFFu;
+                    const U4 prod = gfmul16(lds_multab(mt, c), v);
+                    lds_xor16(acc + (size_t)s * B + gl * 16, prod, h);
+                }
+            }
+        }
+    };
+
+    // ---- phase A: stream the received rows once
+    for (int j0 = wave * R * RPW; j0 < n; j0 += nw * R * RPW) {
+        U4 v[R];
+        uint32_t ew[R][KQ];
+        int cn[R];
+        int kind[R];  // 0 nothing, 1 received row, 2 erased and never solved (written as 0)
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int j = j0 + r * RPW + g;
+            kind[r] = 0; cn[r] = 0;
+            v[r] = U4{0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < KQ; q++) ew[r][q] = 0;
+            if (j < n) {
+                if (!er[j]) {
+                    kind[r] = 1;
+                    v[r] = *reinterpret_cast<const U4 *>(fin + (int64_t)j * S);
+                    cn[r] = scnt[j];
+#pragma unroll
+                    for (int q = 0; q < KQ; q++) {
+                        const int idx = gl + q * LPR;
+                        if (idx < cdw) ew[r][q] = spad[(int64_t)j * cdw + idx];
+                    }
+                } else if (!((solved[j >> 5] >> (j & 31)) & 1u)) {
+                    kind[r] = 2;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int j = j0 + r * RPW + g;
+            if (kind[r]) *reinterpret_cast<U4 *>(fout + (int64_t)j * S) = v[r];
+            scatter(v[r], cn[r], ew[r]);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase B: finalise the solved symbols level by level and scatter them on
+    for (int L = 1; L <= nlev; L++) {
+        const int s0 = lvlend[L - 1], s1 = lvlend[L];
+        for (int sb = s0 + wave * RPW; sb < s1; sb += nw * RPW) {
+            const int s = sb + g;
+            U4 val = {0, 0, 0, 0};
+            uint32_t ew[KQ];
+            int cn = 0;
+#pragma unroll
+            for (int q = 0; q < KQ; q++) ew[q] = 0;
+            if (s < s1) {
+                const int t = tgt[s];
+                const U4 a16 = *reinterpret_cast<const U4 *>(acc + (size_t)s * B + gl * 16);
+                val = gfmul16(lds_multab(mt, invc[s]), a16);
+                *reinterpret_cast<U4 *>(fout + (int64_t)t * S) = val;
+                cn = scnt[t];
+#pragma unroll
+                for (int q = 0; q < KQ; q++) {
+                    const int idx = gl + q * LPR;
+                    if (idx < cdw) ew[q] = spad[(int64_t)t * cdw + idx];
+                }
+            }
+            scatter(val, cn, ew);
         }
         __syncthreads();
     }
@@ -691,7 +910,7 @@ hipError_t upload_constants(hipStream_t s)
 
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
-static PeelLds make_peel_lds(const DevCode &cd, bool fused, int wpb)
+static PeelLds make_peel_lds(const DevCode &cd, bool fused, int wpb, bool srclists = false)
 {
     PeelLds L{};
     int off = 0;
@@ -706,6 +925,7 @@ static PeelLds make_peel_lds(const DevCode &cd, bool fused, int wpb)
     L.steps = w; w += align_up(4 * cd.m, 16);
     L.slvl = w; w += align_up(2 * cd.m, 16);
     L.sorted = w; w += align_up(4 * cd.m, 16);
+    L.cnt = w; if (srclists) w += align_up(4 * cd.n, 16);
     L.wave_stride = w;
     L.total = off + wpb * w;
     return L;
@@ -745,10 +965,53 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     if (!fused && !d.flags_only && (d.S % 16) != 0) return set_error(ctx, LDPC_AMD_EUNSUP, "S must be 1 or a multiple of 16 (got %d)", d.S);
     if (d.max_sweeps < 1) return set_error(ctx, LDPC_AMD_EINVAL, "max_sweeps must be >= 1");
 
+    // bound the per-call workspaces: long batches are processed in chunks of frames
+    const int64_t kChunk = 16384;
+    if (d.nframes > kChunk) {
+        for (int64_t f0 = 0; f0 < d.nframes; f0 += kChunk) {
+            DecodeArgs c = d;
+            c.nframes = std::min(kChunk, d.nframes - f0);
+            if (d.sym) c.sym = d.sym + f0 * (int64_t)d.in_rows * d.S;
+            if (d.erased) c.erased = d.erased + f0 * cd.n;
+            if (d.out) c.out = d.out + f0 * (int64_t)cd.n * d.S;
+            if (d.sweeps) c.sweeps = d.sweeps + f0;
+            if (d.residual) c.residual = d.residual + f0;
+            if (d.status) c.status = d.status + f0;
+            if (d.residual_sys) c.residual_sys = d.residual_sys + f0;
+            int rcc = launch_decode(ctx, c);
+            if (rcc) return rcc;
+        }
+        return LDPC_AMD_OK;
+    }
+
+    // packet path: scatter kernel (rows read once, accumulators in LDS) unless the code's columns are too
+    // heavy for the padded per-source lists, or LDPC_AMD_APPLY=gather asks for the gather kernel (A/B runs)
+    const char *apply_env = getenv("LDPC_AMD_APPLY");
+    const bool want_gather = apply_env && strcmp(apply_env, "gather") == 0;
+    int lpr = 0, nslices = 0, scat_lds = 0;
+    ScatterArgs sa{};
+    if (!fused && !d.flags_only && !want_gather && cd.maxcoldeg <= 16) {
+        int B = 256;
+        while (B > 16 && (d.S % B) != 0) B >>= 1;
+        for (;; B >>= 1) {
+            int off = 0;
+            sa.lds_acc = off; off += align_up(cd.m * B, 16);
+            sa.lds_tgt = off; off += align_up(2 * cd.m, 16);
+            sa.lds_invc = off; off += align_up(cd.m, 16);
+            sa.lds_lvlend = off; off += align_up(2 * (cd.m + 2), 16);
+            sa.lds_solved = off; off += align_up((cd.n + 31) / 32 * 4, 16);
+            sa.lds_mt = off; off += 8192;
+            scat_lds = off;
+            if (off <= 156 * 1024 || B == 16) break;
+        }
+        if (scat_lds <= kLdsMax) { lpr = B / 16; nslices = d.S / B; }
+    }
+    const bool use_scatter = lpr > 0;
+
     // workgroup shape: as many frames per workgroup as fit comfortably in LDS
     int wpb = 4;
-    PeelLds L = make_peel_lds(cd, fused, wpb);
-    while (wpb > 1 && L.total > 80 * 1024) { wpb >>= 1; L = make_peel_lds(cd, fused, wpb); }
+    PeelLds L = make_peel_lds(cd, fused, wpb, use_scatter);
+    while (wpb > 1 && L.total > 96 * 1024) { wpb >>= 1; L = make_peel_lds(cd, fused, wpb, use_scatter); }
     if (L.total > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "code too large for LDS (%d bytes)", L.total);
 
     const int64_t nf = d.nframes;
@@ -774,13 +1037,42 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     } else {
         const size_t hdr = (size_t)nf * 2 * 4, st = (size_t)nf * cd.m * 4, le = (size_t)nf * (cd.m + 1) * 2;
         const size_t o1 = (hdr + 255) & ~(size_t)255, o2 = (o1 + st + 255) & ~(size_t)255;
-        if ((rc = scratch_reserve(ctx, ctx->sched, o2 + le))) return rc;
+        const size_t o3 = (o2 + le + 255) & ~(size_t)255;
+        const size_t sc = use_scatter ? (size_t)nf * cd.n : 0, sp = use_scatter ? (size_t)nf * cd.n * cd.maxcoldeg * 4 : 0;
+        const size_t o4 = (o3 + sc + 255) & ~(size_t)255;
+        if ((rc = scratch_reserve(ctx, ctx->sched, o4 + sp))) return rc;
         unsigned char *base = (unsigned char *)ctx->sched.p;
         pa.sched_hdr = (uint32_t *)base; pa.sched_steps = (uint32_t *)(base + o1); pa.sched_lvlend = (uint16_t *)(base + o2);
+        if (use_scatter) { pa.src_cnt = base + o3; pa.src_pad = (uint32_t *)(base + o4); }
         hipEvent_t ev = prof_begin(ctx);
         LDPC_HIP_TRY(ctx, launch_peel_t<false>(pa, wpb, ctx->stream));
         prof_end(ctx, LDPC_AMD_PROF_PEEL, ev);
 
+        if (use_scatter) {
+            sa.code = cd; sa.S = d.S; sa.nslices = nslices; sa.nframes = nf; sa.sym = d.sym; sa.erased = d.erased; sa.out = d.out;
+            sa.sched_hdr = pa.sched_hdr; sa.sched_steps = pa.sched_steps; sa.sched_lvlend = pa.sched_lvlend;
+            sa.src_cnt = pa.src_cnt; sa.src_pad = pa.src_pad;
+            const dim3 grid((unsigned)(nf * nslices));
+            ev = prof_begin(ctx);
+#define LDPC_SCATTER_CASE(N, T)                                                                              \
+    case N: {                                                                                                \
+        auto kfn = ldpc_scatter_kernel<N>;                                                                   \
+        LDPC_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                           \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, scat_lds));        \
+        hipLaunchKernelGGL(kfn, grid, dim3(T), (size_t)scat_lds, ctx->stream, sa);                           \
+        break;                                                                                               \
+    }
+            switch (lpr) {
+                LDPC_SCATTER_CASE(16, 1024)
+                LDPC_SCATTER_CASE(8, 1024)
+                LDPC_SCATTER_CASE(4, 512)
+                LDPC_SCATTER_CASE(2, 512)
+                LDPC_SCATTER_CASE(1, 256)
+            }
+#undef LDPC_SCATTER_CASE
+            LDPC_HIP_TRY(ctx, hipGetLastError());
+            prof_end(ctx, LDPC_AMD_PROF_APPLY, ev);
+        } else {
         ApplyArgs aa{};
         aa.code = cd; aa.S = d.S; aa.nframes = nf; aa.sym = d.sym; aa.erased = d.erased; aa.in_rows = d.in_rows; aa.out = d.out;
         aa.sched_hdr = pa.sched_hdr; aa.sched_steps = pa.sched_steps; aa.sched_lvlend = pa.sched_lvlend;
@@ -789,6 +1081,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         hipLaunchKernelGGL(ldpc_apply_kernel, dim3((unsigned)nf), dim3(512), lds, ctx->stream, aa);
         LDPC_HIP_TRY(ctx, hipGetLastError());
         prof_end(ctx, LDPC_AMD_PROF_APPLY, ev);
+        }
     }
 
     if (d.do_ml) {
