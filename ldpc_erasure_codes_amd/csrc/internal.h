@@ -86,6 +86,7 @@ struct ldpc_amd_ctx {
     ldpc_amd::Scratch mlws;     // ML stage matrices
     ldpc_amd::Scratch mlstate;  // residual erasure masks of the frames handed to the ML stage
     ldpc_amd::Scratch mllist;   // [1 + nframes] int32: count, frame ids
+    ldpc_amd::Scratch biglist;  // [1 + nframes] int32: frames with many steps (scatter tier 2)
     ldpc_amd::Scratch stage_in, stage_er, stage_out, stage_i32;  // host-pointer staging
     ldpc_amd::Scratch rsws;
     // FPGA-harness emulation state (ldpc_amd_data_in / _ldpc_erasure_decoder / _data_out)

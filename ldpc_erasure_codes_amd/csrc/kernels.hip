@@ -181,6 +181,8 @@ struct PeelArgs {
     uint32_t *sched_steps;  // [nframes][m]
     uint16_t *sched_lvlend; // [nframes][m+1]
     // packet path, scatter form: for every source symbol j the (slot, coefficient) pairs of the steps it feeds
+    int32_t *big_list;      // [0] = count, [1..] frames with more than tcap steps (scatter tier 2), or nullptr
+    int tcap;
     uint8_t *src_cnt;       // [nframes][n]              number of pairs of symbol j  (or nullptr)
     uint32_t *src_pad;      // [nframes][n][maxcoldeg]   slot | coef << 16, first src_cnt entries valid
     // ML hand-off
@@ -288,6 +290,7 @@ __global__ __launch_bounds__(256) void ldpc_peel_kernel(PeelArgs a)
         if (lane == 0) {
             a.sched_hdr[2 * f] = (uint32_t)nsteps;
             a.sched_hdr[2 * f + 1] = (uint32_t)maxlvl;
+            if (a.big_list && nsteps > a.tcap) a.big_list[1 + atomicAdd(&a.big_list[0], 1)] = (int32_t)f;
         }
         uint32_t *gs = a.sched_steps + f * m;
         for (int i = lane; i < nsteps; i += kWave) gs[i] = sorted[i];
@@ -296,8 +299,9 @@ __global__ __launch_bounds__(256) void ldpc_peel_kernel(PeelArgs a)
         if (!a.src_cnt) return;
         // Transpose the used checks: symbol j -> list of (slot of the step it feeds, H(row, j)).  The slot is
         // the step's position in level order.  Every neighbour of a used check except its target is a source.
+        // four 8-bit counters per LDS word (a symbol feeds at most maxcoldeg <= 16 steps)
         uint32_t *cnt = reinterpret_cast<uint32_t *>(wbase + a.lds.cnt);
-        for (int j = lane; j < n; j += kWave) cnt[j] = 0;
+        for (int j = lane; j < (n + 3) / 4; j += kWave) cnt[j] = 0;
         wave_sync();
         const int cdw = cd.maxcoldeg;
         uint32_t *gp = a.src_pad + f * (int64_t)n * cdw;
@@ -311,14 +315,15 @@ __global__ __launch_bounds__(256) void ldpc_peel_kernel(PeelArgs a)
                 const uint32_t c = ell_col[t * mpad + row];
                 if (c != 0xFFFFu && c != tgt) {
                     const uint32_t coef = (cd.edges[e0 + t] >> 16) & 0xFFu;
-                    const uint32_t pos = atomicAdd(&cnt[c], 1u);
+                    const uint32_t sh = 8u * (c & 3u);
+                    const uint32_t pos = (atomicAdd(&cnt[c >> 2], 1u << sh) >> sh) & 0xFFu;
                     gp[(int64_t)c * cdw + pos] = (uint32_t)s | (coef << 16);
                 }
             }
         }
         wave_sync();
         uint8_t *gc = a.src_cnt + f * (int64_t)n;
-        for (int j = lane; j < n; j += kWave) gc[j] = (uint8_t)cnt[j];
+        for (int j = lane; j < n; j += kWave) gc[j] = reinterpret_cast<const uint8_t *>(cnt)[j];
         return;
     }
 
@@ -483,6 +488,8 @@ struct ScatterArgs {
     const uint16_t *sched_lvlend;
     const uint8_t *src_cnt;
     const uint32_t *src_pad;
+    int tcap;                 // tier 1 handles frames with at most tcap steps (its LDS holds tcap accumulators)
+    const int32_t *big_list;  // tier 2: [0] = count, [1..] ids of the frames with more steps; nullptr in tier 1
     int lds_acc, lds_tgt, lds_invc, lds_lvlend, lds_solved, lds_mt;
 };
 
@@ -505,18 +512,39 @@ __device__ __forceinline__ void lds_xor16(unsigned char *p, const U4 &v, int h)
     __hip_atomic_fetch_xor(q + (1 - h), h ? lo : hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <int LPR>
-__global__ __launch_bounds__(1024) void ldpc_scatter_kernel(ScatterArgs a)
+template <bool NT>
+__device__ __forceinline__ U4 stream_load16(const uint8_t *p)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    if (NT) {
+        const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+        U4 v;
+        v.x = __builtin_nontemporal_load(q); v.y = __builtin_nontemporal_load(q + 1);
+        v.z = __builtin_nontemporal_load(q + 2); v.w = __builtin_nontemporal_load(q + 3);
+        return v;
+    }
+    return *reinterpret_cast<const U4 *>(p);
+}
+
+template <bool NT>
+__device__ __forceinline__ void stream_store16(uint8_t *p, const U4 &v)
+{
+    if (NT) {
+        uint32_t *q = reinterpret_cast<uint32_t *>(p);
+        __builtin_nontemporal_store(v.x, q); __builtin_nontemporal_store(v.y, q + 1);
+        __builtin_nontemporal_store(v.z, q + 2); __builtin_nontemporal_store(v.w, q + 3);
+    } else {
+        *reinterpret_cast<U4 *>(p) = v;
+    }
+}
+
+template <int LPR, int R, bool NT>
+__device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned char *smem, const int64_t f, const int sl)
+{
     constexpr int RPW = 64 / LPR;              // row pieces per wave instruction
     constexpr int KQ = (16 + LPR - 1) / LPR;   // edge words held per lane (maxcoldeg <= 16)
-    constexpr int R = (LPR >= 8) ? 4 : 1;      // row pieces in flight per lane
-    constexpr int B = 16 * LPR;                // bytes of every row handled by this workgroup
+    constexpr int B = 16 * LPR;                // bytes of every row handled by this workgroup (R pieces in flight per lane)
     const DevCode &cd = a.code;
     const int n = cd.n, S = a.S, cdw = cd.maxcoldeg;
-    const int64_t f = blockIdx.x / a.nslices;
-    const int sl = (int)(blockIdx.x % a.nslices);
     const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
     const int lane = lane_id(), wave = wave_id(), nw = nthr >> 6;
     const int g = lane / LPR, gl = lane % LPR, h = (lane >> 3) & 1;
@@ -591,7 +619,7 @@ __global__ __launch_bounds__(1024) void ldpc_scatter_kernel(ScatterArgs a)
             if (j < n) {
                 if (!er[j]) {
                     kind[r] = 1;
-                    v[r] = *reinterpret_cast<const U4 *>(fin + (int64_t)j * S);
+                    v[r] = stream_load16<NT>(fin + (int64_t)j * S);
                     cn[r] = scnt[j];
 #pragma unroll
                     for (int q = 0; q < KQ; q++) {
@@ -606,7 +634,7 @@ __global__ __launch_bounds__(1024) void ldpc_scatter_kernel(ScatterArgs a)
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int j = j0 + r * RPW + g;
-            if (kind[r]) *reinterpret_cast<U4 *>(fout + (int64_t)j * S) = v[r];
+            if (kind[r]) stream_store16<NT>(fout + (int64_t)j * S, v[r]);
             scatter(v[r], cn[r], ew[r]);
         }
     }
@@ -626,7 +654,7 @@ __global__ __launch_bounds__(1024) void ldpc_scatter_kernel(ScatterArgs a)
                 const int t = tgt[s];
                 const U4 a16 = *reinterpret_cast<const U4 *>(acc + (size_t)s * B + gl * 16);
                 val = gfmul16(lds_multab(mt, invc[s]), a16);
-                *reinterpret_cast<U4 *>(fout + (int64_t)t * S) = val;
+                stream_store16<NT>(fout + (int64_t)t * S, val);
                 cn = scnt[t];
 #pragma unroll
                 for (int q = 0; q < KQ; q++) {
@@ -637,6 +665,30 @@ __global__ __launch_bounds__(1024) void ldpc_scatter_kernel(ScatterArgs a)
             scatter(val, cn, ew);
         }
         __syncthreads();
+    }
+}
+
+// Tier 1: one workgroup per (frame, slice); frames with more than tcap steps are left to tier 2.
+// WPE = waves per SIMD the register allocation must allow (8 -> two 1024-thread workgroups per CU).
+template <int LPR, int R, bool NT, int WPE>
+__global__ __launch_bounds__(1024, WPE) void ldpc_scatter_kernel(ScatterArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int64_t f = blockIdx.x / a.nslices;
+    const int sl = (int)(blockIdx.x % a.nslices);
+    if ((int)a.sched_hdr[2 * f] > a.tcap) return;
+    scatter_frame<LPR, R, NT>(a, smem, f, sl);
+}
+
+// Tier 2: the few frames with many steps (LDS sized for m accumulators), grid-stride over the compacted list.
+template <int LPR, int R, bool NT>
+__global__ __launch_bounds__(1024) void ldpc_scatter_big_kernel(ScatterArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int64_t items = (int64_t)a.big_list[0] * a.nslices;
+    for (int64_t it = blockIdx.x; it < items; it += gridDim.x) {
+        __syncthreads();
+        scatter_frame<LPR, R, NT>(a, smem, a.big_list[1 + it / a.nslices], (int)(it % a.nslices));
     }
 }
 
@@ -925,7 +977,7 @@ static PeelLds make_peel_lds(const DevCode &cd, bool fused, int wpb, bool srclis
     L.steps = w; w += align_up(4 * cd.m, 16);
     L.slvl = w; w += align_up(2 * cd.m, 16);
     L.sorted = w; w += align_up(4 * cd.m, 16);
-    L.cnt = w; if (srclists) w += align_up(4 * cd.n, 16);
+    L.cnt = w; if (srclists) w += align_up(cd.n + 4, 16);
     L.wave_stride = w;
     L.total = off + wpb * w;
     return L;
@@ -956,6 +1008,115 @@ static hipError_t launch_peel_t(const PeelArgs &a, int wpb, hipStream_t s)
 }
 
 static const int kLdsMax = 160 * 1024;
+
+// ---- scatter kernel launch plan ---------------------------------------------------------------------------
+struct ScatterPlan {
+    int lpr = 0;        // 16-byte lanes per row piece (B = 16 * lpr bytes of every row per workgroup), 0 = unusable
+    int nslices = 0;    // S / B
+    int tcap = 0;       // tier 1 handles frames with <= tcap steps
+    bool two_tier = false;
+    int lds1 = 0, lds2 = 0;                       // dynamic LDS bytes of tier 1 / tier 2
+    int o_tgt = 0, o_invc = 0, o_lvl = 0, o_sol = 0, o_mt = 0;  // offsets behind the accumulators (relative)
+};
+
+static int scatter_tail_bytes(const DevCode &cd, ScatterPlan &p)
+{
+    int off = 0;
+    p.o_tgt = off; off += align_up(2 * cd.m, 16);
+    p.o_invc = off; off += align_up(cd.m, 16);
+    p.o_lvl = off; off += align_up(2 * (cd.m + 2), 16);
+    p.o_sol = off; off += align_up((cd.n + 31) / 32 * 4, 16);
+    p.o_mt = off; off += 8192;
+    return off;
+}
+
+static ScatterPlan plan_scatter(const DevCode &cd, int S)
+{
+    ScatterPlan p;
+    int B = 256;
+    while (B > 16 && (S % B) != 0) B >>= 1;
+    const int tail = scatter_tail_bytes(cd, p);
+    while (B > 16 && cd.m * B + tail > 156 * 1024) B >>= 1;
+    if (cd.m * B + tail > kLdsMax) return p;
+    p.lpr = B / 16;
+    p.nslices = S / B;
+    p.lds2 = cd.m * B + tail;
+    // Two workgroups per CU (each half of the 160 KB) hide one workgroup's set-up and level phase behind the
+    // other's streaming phase: possible when the accumulators of the typical frame fit in half the LDS.
+    const char *env = getenv("LDPC_AMD_SCATTER_TIERS");
+    const bool allow = !(env && atoi(env) == 1);
+    const int half = kLdsMax / 2;
+    int tcap = (half - tail) / B;
+    if (allow && p.lpr >= 8 && tcap >= cd.m / 4 && tcap < cd.m) {
+        p.two_tier = true;
+        p.tcap = tcap;
+        p.lds1 = tcap * B + tail;
+    } else {
+        p.tcap = cd.m;
+        p.lds1 = p.lds2;
+    }
+    return p;
+}
+
+static void scatter_set_lds(ScatterArgs &sa, const ScatterPlan &p, int nacc)
+{
+    const int base = align_up(nacc * 16 * p.lpr, 16);
+    sa.lds_acc = 0;
+    sa.lds_tgt = base + p.o_tgt; sa.lds_invc = base + p.o_invc; sa.lds_lvlend = base + p.o_lvl;
+    sa.lds_solved = base + p.o_sol; sa.lds_mt = base + p.o_mt;
+}
+
+template <int LPR>
+static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterArgs sa, const int32_t *big_list)
+{
+    constexpr int R = (LPR >= 8) ? 4 : 1;
+    constexpr int THREADS = (LPR >= 8) ? 1024 : (LPR >= 2 ? 512 : 256);
+    const char *env_nt = getenv("LDPC_AMD_SCATTER_NT");
+    const bool nt = env_nt ? atoi(env_nt) != 0 : true;
+    const dim3 grid((unsigned)(sa.nframes * sa.nslices));
+    // tier 1
+    sa.tcap = p.tcap; sa.big_list = nullptr;
+    scatter_set_lds(sa, p, p.tcap);
+#define LDPC_SCATTER_T1(NTV, WPE)                                                                          \
+    {                                                                                                        \
+        auto kfn = ldpc_scatter_kernel<LPR, R, NTV, WPE>;                                                    \
+        LDPC_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                           \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, p.lds1));          \
+        hipLaunchKernelGGL(kfn, grid, dim3(THREADS), (size_t)p.lds1, ctx->stream, sa);                       \
+    }
+    if (p.two_tier) { if (nt) LDPC_SCATTER_T1(true, 8) else LDPC_SCATTER_T1(false, 8) }
+    else { if (nt) LDPC_SCATTER_T1(true, 4) else LDPC_SCATTER_T1(false, 4) }
+#undef LDPC_SCATTER_T1
+    LDPC_HIP_TRY(ctx, hipGetLastError());
+    if (p.two_tier) {
+        sa.tcap = sa.code.m; sa.big_list = big_list;
+        scatter_set_lds(sa, p, sa.code.m);
+        const dim3 g2((unsigned)std::min<int64_t>(sa.nframes * sa.nslices, ctx->sm_count));
+#define LDPC_SCATTER_T2(NTV)                                                                               \
+    {                                                                                                        \
+        auto kfn = ldpc_scatter_big_kernel<LPR, R, NTV>;                                                     \
+        LDPC_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                           \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, p.lds2));          \
+        hipLaunchKernelGGL(kfn, g2, dim3(THREADS), (size_t)p.lds2, ctx->stream, sa);                         \
+    }
+        if (nt) LDPC_SCATTER_T2(true) else LDPC_SCATTER_T2(false)
+#undef LDPC_SCATTER_T2
+        LDPC_HIP_TRY(ctx, hipGetLastError());
+    }
+    return LDPC_AMD_OK;
+}
+
+static int launch_scatter(ldpc_amd_ctx *ctx, const ScatterPlan &p, const ScatterArgs &sa, const int32_t *big_list)
+{
+    switch (p.lpr) {
+        case 16: return launch_scatter_lpr<16>(ctx, p, sa, big_list);
+        case 8: return launch_scatter_lpr<8>(ctx, p, sa, big_list);
+        case 4: return launch_scatter_lpr<4>(ctx, p, sa, big_list);
+        case 2: return launch_scatter_lpr<2>(ctx, p, sa, big_list);
+        case 1: return launch_scatter_lpr<1>(ctx, p, sa, big_list);
+    }
+    return set_error(ctx, LDPC_AMD_EUNSUP, "scatter: bad plan");
+}
 
 int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
 {
@@ -988,25 +1149,9 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     // heavy for the padded per-source lists, or LDPC_AMD_APPLY=gather asks for the gather kernel (A/B runs)
     const char *apply_env = getenv("LDPC_AMD_APPLY");
     const bool want_gather = apply_env && strcmp(apply_env, "gather") == 0;
-    int lpr = 0, nslices = 0, scat_lds = 0;
-    ScatterArgs sa{};
-    if (!fused && !d.flags_only && !want_gather && cd.maxcoldeg <= 16) {
-        int B = 256;
-        while (B > 16 && (d.S % B) != 0) B >>= 1;
-        for (;; B >>= 1) {
-            int off = 0;
-            sa.lds_acc = off; off += align_up(cd.m * B, 16);
-            sa.lds_tgt = off; off += align_up(2 * cd.m, 16);
-            sa.lds_invc = off; off += align_up(cd.m, 16);
-            sa.lds_lvlend = off; off += align_up(2 * (cd.m + 2), 16);
-            sa.lds_solved = off; off += align_up((cd.n + 31) / 32 * 4, 16);
-            sa.lds_mt = off; off += 8192;
-            scat_lds = off;
-            if (off <= 156 * 1024 || B == 16) break;
-        }
-        if (scat_lds <= kLdsMax) { lpr = B / 16; nslices = d.S / B; }
-    }
-    const bool use_scatter = lpr > 0;
+    ScatterPlan plan{};
+    if (!fused && !d.flags_only && !want_gather && cd.maxcoldeg <= 16) plan = plan_scatter(cd, d.S);
+    const bool use_scatter = plan.lpr > 0;
 
     // workgroup shape: as many frames per workgroup as fit comfortably in LDS
     int wpb = 4;
@@ -1019,6 +1164,10 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     if ((rc = scratch_reserve(ctx, ctx->mllist, sizeof(int32_t) * (size_t)(nf + 1)))) return rc;
     if (d.do_ml && (rc = scratch_reserve(ctx, ctx->mlstate, (size_t)nf * cd.n))) return rc;
     LDPC_HIP_TRY(ctx, hipMemsetAsync(ctx->mllist.p, 0, sizeof(int32_t), ctx->stream));
+    if (use_scatter && plan.two_tier) {
+        if ((rc = scratch_reserve(ctx, ctx->biglist, sizeof(int32_t) * (size_t)(nf + 1)))) return rc;
+        LDPC_HIP_TRY(ctx, hipMemsetAsync(ctx->biglist.p, 0, sizeof(int32_t), ctx->stream));
+    }
 
     PeelArgs pa{};
     pa.code = cd; pa.lds = L; pa.nframes = nf; pa.sym = d.sym; pa.erased = d.erased; pa.in_rows = d.in_rows;
@@ -1043,34 +1192,22 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         if ((rc = scratch_reserve(ctx, ctx->sched, o4 + sp))) return rc;
         unsigned char *base = (unsigned char *)ctx->sched.p;
         pa.sched_hdr = (uint32_t *)base; pa.sched_steps = (uint32_t *)(base + o1); pa.sched_lvlend = (uint16_t *)(base + o2);
-        if (use_scatter) { pa.src_cnt = base + o3; pa.src_pad = (uint32_t *)(base + o4); }
+        if (use_scatter) {
+            pa.src_cnt = base + o3; pa.src_pad = (uint32_t *)(base + o4);
+            pa.tcap = plan.tcap;
+            pa.big_list = plan.two_tier ? (int32_t *)ctx->biglist.p : nullptr;
+        }
         hipEvent_t ev = prof_begin(ctx);
         LDPC_HIP_TRY(ctx, launch_peel_t<false>(pa, wpb, ctx->stream));
         prof_end(ctx, LDPC_AMD_PROF_PEEL, ev);
 
         if (use_scatter) {
-            sa.code = cd; sa.S = d.S; sa.nslices = nslices; sa.nframes = nf; sa.sym = d.sym; sa.erased = d.erased; sa.out = d.out;
+            ScatterArgs sa{};
+            sa.code = cd; sa.S = d.S; sa.nslices = plan.nslices; sa.nframes = nf; sa.sym = d.sym; sa.erased = d.erased; sa.out = d.out;
             sa.sched_hdr = pa.sched_hdr; sa.sched_steps = pa.sched_steps; sa.sched_lvlend = pa.sched_lvlend;
             sa.src_cnt = pa.src_cnt; sa.src_pad = pa.src_pad;
-            const dim3 grid((unsigned)(nf * nslices));
             ev = prof_begin(ctx);
-#define LDPC_SCATTER_CASE(N, T)                                                                              \
-    case N: {                                                                                                \
-        auto kfn = ldpc_scatter_kernel<N>;                                                                   \
-        LDPC_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                           \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, scat_lds));        \
-        hipLaunchKernelGGL(kfn, grid, dim3(T), (size_t)scat_lds, ctx->stream, sa);                           \
-        break;                                                                                               \
-    }
-            switch (lpr) {
-                LDPC_SCATTER_CASE(16, 1024)
-                LDPC_SCATTER_CASE(8, 1024)
-                LDPC_SCATTER_CASE(4, 512)
-                LDPC_SCATTER_CASE(2, 512)
-                LDPC_SCATTER_CASE(1, 256)
-            }
-#undef LDPC_SCATTER_CASE
-            LDPC_HIP_TRY(ctx, hipGetLastError());
+            if ((rc = launch_scatter(ctx, plan, sa, (const int32_t *)ctx->biglist.p))) return rc;
             prof_end(ctx, LDPC_AMD_PROF_APPLY, ev);
         } else {
         ApplyArgs aa{};

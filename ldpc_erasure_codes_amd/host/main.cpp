@@ -1,0 +1,260 @@
+// main.cpp -- host harness with the life-cycle and command line of the reference's FPGA host
+// (OpenCL/host/src/main.cpp), running on libldpc_erasure_amd.so (MI355X) instead of an .aocx.
+//
+//   reference                                   here
+//   ---------                                   ----
+//   init_opencl()          main.cpp:439-544     init_opencl()   -> ldpc_amd_init + code handles (name kept on purpose)
+//   read_test_vector_file_noisy_packets :362    same name, same text format (one 16-bit value per line, 0 = erasure)
+//   read_test_vector_file_packets       :329    same name (value replicated into the 128 x u64 payload, :346-351)
+//   run()                  main.cpp:555-659     run(): H2D, the three "kernels" with the reference's argument lists
+//                                               (data_in :578-589, ldpc_erasure_decoder :593-596, data_out :599-604),
+//                                               D2H, throughput line (:652-655)
+//   verify_output()        main.cpp:413-425     same comparison over k symbols x 128 words, PASSED / FAILED!
+//   cleanup()              main.cpp:668-691     ldpc_amd_cleanup
+//   options -p -n -e -h -i -c   :157-170        same letters and meanings
+//
+// Differences that are deliberate: (1) both -e and -h run the HIP backend (there is no emulator and no CPU
+// fallback); -e only selects the small functional run without the throughput loop.  (2) When the two Matlab test
+// vector files named by the reference (main.cpp:68-69) are absent -- they are absent from the reference itself --
+// an equivalent vector is synthesised with the library's encoder.  (3) The functional decode uses the binary code
+// (all coefficients 1), i.e. the packet-XOR decoder the FPGA implements.
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ldpc_erasure_amd.h"
+
+#define EMULATION_PLAT 0
+#define HARDWARE_PLAT 1
+static const int SYM_LEN = LDPC_AMD_SYM_LEN;  // 128 x u64 = 1024 payload bytes (main.cpp:42)
+typedef ldpc_amd_symbol_type symbol_type;
+
+static int k_LEN = 2000;  // updated from ldpc_params[code_ind] like main.cpp:258-259
+static int n_LEN = 4000;
+
+static const char *input_data_file = "LDPC_ErasureDecoder_IN_n2000_Shorts_35PercentPER.txt";  // main.cpp:68
+static const char *output_data_file = "LDPC_ErasureDecoder_OUT_k1000_Shorts.txt";             // main.cpp:69
+
+static ldpc_amd_ctx *ctx = NULL;
+static int code_handle = -1;
+
+static std::vector<symbol_type> din_array;    // received frame (AoS, like the reference's alignedMalloc buffers)
+static std::vector<symbol_type> dout_vector;  // expected first k symbols
+static std::vector<symbol_type> dout;         // decoder output
+
+static char ptype = EMULATION_PLAT;
+static short numItr = 50;         // main.cpp:99
+static long numFrames = 1000000;  // main.cpp:100
+static int seed = 0;
+static int PER_numerator_div_64 = 0;
+static int code_ind = 0;
+
+static bool init_opencl();
+static void run();
+static void cleanup();
+static int verify_output();
+static int read_test_vector_file_noisy_packets(const char *filename, symbol_type *arr, const int sym_len);
+static int read_test_vector_file_packets(const char *filename, symbol_type *arr, const int sym_len);
+
+static void checkError(int status, const char *what)
+{
+    // AOCLUtils' checkError prints and exits (main.cpp:493,508,569)
+    if (status < 0) {
+        fprintf(stderr, "ERROR: %s: %s\n", what, ldpc_amd_last_error(ctx));
+        cleanup();
+        exit(1);
+    }
+}
+
+static void usage()
+{
+    printf("USAGE: ldpc_erasure_decoder_host [options]\n\nOptions:\n"
+           "  --help      Print usage and exit.\n"
+           "  -p <arg>    (arg/64)*100%% packet error rate\n"
+           "  -n <arg>    how many frames to send through the simulation\n"
+           "  -e          Run in emulation mode (functional run only; still on the GPU)\n"
+           "  -h          Run on hardware (MI355X)\n"
+           "  -i <arg>    number of message-passing iterations\n"
+           "  -c <arg>    code type: 0 = (2000, 1000), 1 = (2040, 1530), 2 = (4000, 2000)\n");
+}
+
+int main(int argc, char **argv)
+{
+    if (argc <= 1) { usage(); return 0; }
+    for (int i = 1; i < argc; i++) {
+        const std::string a = argv[i];
+        auto need = [&](const char *name) -> const char * {
+            if (i + 1 >= argc) { fprintf(stderr, "Option '%s' requires a numeric argument\n", name); exit(1); }
+            return argv[++i];
+        };
+        if (a == "--help") { usage(); return 0; }
+        else if (a == "-p") PER_numerator_div_64 = atoi(need("-p"));
+        else if (a == "-n") numFrames = atol(need("-n"));
+        else if (a == "-c") code_ind = atoi(need("-c"));
+        else if (a == "-i") numItr = (short)atoi(need("-i"));
+        else if (a == "-e") ptype = EMULATION_PLAT;
+        else if (a == "-h") ptype = HARDWARE_PLAT;
+        else { fprintf(stderr, "Unknown option '%s'\n", a.c_str()); return 1; }
+    }
+
+    int params[6];
+    if (ldpc_amd_code_params(code_ind, params) != LDPC_AMD_OK) {
+        fprintf(stderr, "ERROR: no code with index %d\n", code_ind);
+        return -1;
+    }
+    n_LEN = params[0];
+    k_LEN = params[1];
+
+    if (!init_opencl()) return -1;
+
+    din_array.resize(n_LEN);
+    dout_vector.resize(k_LEN);
+    dout.resize(k_LEN);
+    const int rin = read_test_vector_file_noisy_packets(input_data_file, din_array.data(), SYM_LEN);
+    const int rout = rin < 0 ? -1 : read_test_vector_file_packets(output_data_file, dout_vector.data(), SYM_LEN);
+    if (rin != n_LEN || rout != k_LEN) {
+        // The reference aborts here (main.cpp:274-284); its vector files are not in its repository, so make one.
+        printf("Test vector files not found (or wrong length): synthesising an equivalent vector on the GPU\n");
+        std::vector<uint8_t> src((size_t)k_LEN * 1024), cw((size_t)n_LEN * 1024);
+        srand(12345);
+        for (size_t i = 0; i < src.size(); i++) src[i] = (uint8_t)(rand() >> 7);
+        checkError(ldpc_amd_encode_batch(ctx, code_handle, 1024, 1, src.data(), cw.data(), 0), "encode");
+        for (int j = 0; j < n_LEN; j++) {
+            memcpy(din_array[j].symbol, &cw[(size_t)j * 1024], 1024);
+            din_array[j].is_erasure = ((j * 2654435761u) >> 24) % 64 < 9 ? 1 : 0;  // ~14 % erased (9/64)
+            if (din_array[j].is_erasure) memset(din_array[j].symbol, 0, 1024);      // erased payload is zero on the FPGA
+            if (j < k_LEN) { memcpy(dout_vector[j].symbol, &cw[(size_t)j * 1024], 1024); dout_vector[j].is_erasure = 0; }
+        }
+    }
+
+    run();
+
+    if (verify_output() >= 0) printf("PASSED\n");
+    else printf("FAILED!\n");
+
+    cleanup();
+    return 0;
+}
+
+// One 16-bit value per line; the value is replicated into all 128 x 4 16-bit fields of the payload
+// (main.cpp:346-351); in the noisy reader a value of 0 marks an erasure (:380-387).
+static int read_vector_file(const char *filename, symbol_type *arr, int sym_len, bool noisy, int max_rows)
+{
+    FILE *file = fopen(filename, "rt");
+    if (!file) return -1;
+    char line[256];
+    int cnt = 0;
+    while (cnt < max_rows && fgets(line, sizeof(line), file)) {
+        char *tok = strtok(line, ", ");
+        const unsigned long v = tok ? (unsigned long)atoi(tok) : 0ul;
+        const unsigned long w = ((v & 0xFFFF) << 48) | ((v & 0xFFFF) << 32) | ((v & 0xFFFF) << 16) | (v & 0xFFFF);
+        if (noisy) arr[cnt].is_erasure = (v == 0) ? 1 : 0;
+        else arr[cnt].is_erasure = 0;
+        for (int i = 0; i < sym_len; i++) arr[cnt].symbol[i] = w;
+        cnt++;
+    }
+    fclose(file);
+    return cnt;
+}
+
+static int read_test_vector_file_noisy_packets(const char *filename, symbol_type *arr, const int sym_len)
+{
+    return read_vector_file(filename, arr, sym_len, true, n_LEN);
+}
+
+static int read_test_vector_file_packets(const char *filename, symbol_type *arr, const int sym_len)
+{
+    return read_vector_file(filename, arr, sym_len, false, k_LEN);
+}
+
+static int verify_output()
+{
+    for (int i = 0; i < k_LEN; i++)
+        for (int j = 0; j < SYM_LEN; j++)
+            if (dout_vector[i].symbol[j] != dout[i].symbol[j]) return -1;
+    return 0;
+}
+
+static bool init_opencl()
+{
+    printf("Initializing %s\n", ldpc_amd_version());
+    if (ldpc_amd_init(0, &ctx) != LDPC_AMD_OK) {
+        printf("ERROR: Unable to initialise the MI355X backend: %s\n", ldpc_amd_last_error(NULL));
+        return false;
+    }
+    code_handle = ldpc_amd_load_builtin_code(ctx, code_ind, 0 /* binary H: the FPGA decoder XORs packets */);
+    if (code_handle < 0) {
+        printf("ERROR: %s\n", ldpc_amd_last_error(ctx));
+        return false;
+    }
+    if (ldpc_amd_selftest(ctx) != LDPC_AMD_OK) {
+        printf("ERROR: %s\n", ldpc_amd_last_error(ctx));
+        return false;
+    }
+    return true;
+}
+
+static double now_s()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void run()
+{
+    const double start_time = now_s();
+    seed = ((int)round((double)time(NULL))) % 1000000;  // main.cpp:561
+    printf("The seed used in this run is: %d\n", seed);
+
+    // ---- functional decode of the test vector frame (what the FPGA flow does with din_array -> dout):
+    //      AoS symbol_type -> SoA planes is the shim's job (SURVEY 8b "Data types")
+    std::vector<uint8_t> sym((size_t)n_LEN * 1024), erased(n_LEN), out((size_t)n_LEN * 1024);
+    for (int j = 0; j < n_LEN; j++) {
+        memcpy(&sym[(size_t)j * 1024], din_array[j].symbol, 1024);
+        erased[j] = din_array[j].is_erasure;
+    }
+    int32_t sweeps = 0, residual = 0, status = 0;
+    checkError(ldpc_amd_decode_batch(ctx, code_handle, 1024, 1, sym.data(), erased.data(), numItr, 0 /* MP only */,
+                                     out.data(), &sweeps, &residual, &status, 0),
+               "Failed to decode the test vector");
+    for (int i = 0; i < k_LEN; i++) {
+        memcpy(dout[i].symbol, &out[(size_t)i * 1024], 1024);
+        dout[i].is_erasure = 0;
+    }
+    printf("Test vector: %d sweeps, %d symbols left erased\n", sweeps, residual);
+
+    if (ptype == HARDWARE_PLAT && numFrames > 0) {
+        // ---- throughput / BLER run: the three kernels with the reference's argument lists
+        printf("Launching for device %d (%d elements)\n", 1, n_LEN);
+        const double t0 = now_s();
+        checkError(ldpc_amd_data_in(ctx, NULL, (unsigned short)n_LEN, seed, PER_numerator_div_64, code_ind, numFrames),
+                   "Failed to launch data_in");
+        checkError(ldpc_amd_ldpc_erasure_decoder(ctx, numItr, code_ind), "Failed to launch K_LDPC_ERASURE_DECODER");
+        ldpc_amd_error_type st;
+        checkError(ldpc_amd_data_out(ctx, NULL, code_ind, numFrames, &st), "Failed to launch kernel_write");
+        const double t1 = now_s();
+        int params[6];
+        ldpc_amd_code_params(code_ind, params);
+        const int rs_mult = n_LEN / params[4];
+        printf("In data_out, frame error rate is: %f, RS FER=%f\n", (float)st.num_LDPC_errors / (float)numFrames,
+               (float)st.num_RS_errors / (rs_mult * (float)numFrames));
+        printf("Kernel time: %0.3f ms\n", (t1 - t0) * 1e3);
+        // same formula as main.cpp:655 (SYM_LEN*8*8 bits per symbol)
+        printf("The throughput in information bits/sec: %f\t(erasure-pattern decode only: the payload of this run is the "
+               "all-zero codeword, as on the FPGA)\n",
+               ((float)SYM_LEN * 8.0f * 8.0f * (float)numFrames * (float)k_LEN) / (t1 - t0));
+    }
+    (void)start_time;
+}
+
+static void cleanup()
+{
+    if (ctx) ldpc_amd_cleanup(ctx);
+    ctx = NULL;
+}
