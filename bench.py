@@ -37,6 +37,27 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 SEED_SRC, SEED_ERA = 20261004, 20261005
 
 
+SCATTER_KERNEL = "ldpc_scatter_kernel<16, 4, true, 8>"
+PEEL_S1_KERNEL = "ldpc_peel_kernel<16, true>"
+
+
+def pmc_traffic(kernel, frames, S):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE /
+    WRITE_SIZE passes of this same command, gfx950 correction applied: tools/summarize_profiles.py).  The counters
+    cannot be read from inside this process, so the value is the one measured for the default batch
+    (4096 frames, S = 1024 / 1); None when there is no summary or the shape differs."""
+    path = os.path.join(ROOT, "profiles", "round1_pmc_summary.json")
+    if frames != 4096 or S not in (1, 1024) or not os.path.exists(path):
+        return None
+    try:
+        k = json.load(open(path))["kernels"][kernel]
+    except (KeyError, ValueError):
+        return None
+    if S == 1:  # the S = 1 launches are the large ones of that kernel in the profiled run
+        return 2.0 * k["FETCH_SIZE_KB_max"] * 1024.0 + k["WRITE_SIZE_KB_max"] * 1024.0
+    return k["traffic_bytes"]
+
+
 def alg_bytes_per_frame(n, S):
     # SURVEY.md section 8(d): symbols in + erasure flags in + Msg out + sweeps/residual words
     return 2 * n * S + n + 8
@@ -92,7 +113,7 @@ def cpu_baseline(S, cores, frames_per_core):
 def run_gpu(args, rank, world, local_rank):
     import torch
     import torch.distributed as dist
-    from ldpc_erasure_codes_amd import api, codes
+    from ldpc_erasure_codes_amd import api, codes, sharding
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -129,8 +150,7 @@ def run_gpu(args, rank, world, local_rank):
         sw = torch.empty(F, dtype=torch.int32, device=dev)
         res = torch.empty(F, dtype=torch.int32, device=dev)
         st = torch.empty(F, dtype=torch.int32, device=dev)
-        stat_words = torch.stack([sw, res, st])
-        gathered = torch.empty((world,) + tuple(stat_words.shape), dtype=torch.int32, device=dev) if world > 1 else None
+        counts = [F] * world
         for _ in range(warmup):
             ctx.decode(h, sym, era, out=out, sweeps=sw, residual=res, status=st)
         ctx.get_profile()
@@ -139,17 +159,14 @@ def run_gpu(args, rank, world, local_rank):
         t0 = time.perf_counter()
         for _ in range(steps):
             ctx.decode(h, sym, era, out=out, sweeps=sw, residual=res, status=st)
-        if world > 1:  # the one collective of the job: final gather of the status words over RCCL/xGMI
-            torch.stack([sw, res, st], out=stat_words)
-            dist.all_gather_into_tensor(gathered, stat_words)
+        # the one collective of the job: final gather of the status words (12 B/frame) over RCCL/xGMI
+        parts = sharding.gather_status(torch.stack([sw, res, st]), counts)
         barrier()
         dt = time.perf_counter() - t0
         ctx.set_profiling(False)
         prof = ctx.get_profile()
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+        dt = sharding.max_over_ranks(dt, dev)
+        assert len(parts) == world
         # correctness of what was just timed: every frame of cfg 2 decodes to its codeword
         ok = bool(torch.equal(out, cw)) and int(st.max()) == 0
         hist = torch.bincount(sw, minlength=12).cpu().numpy().tolist()
@@ -173,9 +190,10 @@ def run_gpu(args, rank, world, local_rank):
             "value": fps, "ms_per_step": dt / steps * 1e3, "recovered_GBps": fps * k * S / 1e9, "steps": steps,
             "verified": ok, "sweeps_hist": hist, "ml_trigger_rate": ml_rate,
             "kernel_ms": {kk: (v[0] / max(v[1], 1)) for kk, v in prof.items()},
-            "roofline": {"bound": "hbm", "kernel": "ldpc_apply_kernel" if S > 1 else "ldpc_peel_kernel<16,true>",
+            "roofline": {"bound": "hbm", "kernel": SCATTER_KERNEL if S > 1 else PEEL_S1_KERNEL,
                          "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                         "traffic": None, "alg_bytes_per_launch": ab, "avg_launch_ms": kavg},
+                         "traffic": pmc_traffic(SCATTER_KERNEL if S > 1 else PEEL_S1_KERNEL, F, S),
+                         "alg_bytes_per_launch": ab, "avg_launch_ms": kavg},
             "sample": sample,
         }
     ctx.close()

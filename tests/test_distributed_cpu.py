@@ -1,0 +1,100 @@
+"""N > 1 path on CPU: world_size-2 `gloo` processes run the sharding + final-gather logic of bench.py
+(ldpc_erasure_codes_amd/sharding.py).  The local decode is done by the CPU oracle here (tests may use it);
+on the GPUs the same plumbing wraps the HIP library and RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from ldpc_erasure_codes_amd import sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_frames_partitions_exactly():
+    for total in (0, 1, 7, 4096, 65536, 1001):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                f0, c = sharding.shard_frames(total, r, world)
+                seen.extend(range(f0, f0 + c))
+            assert seen == list(range(total))
+            counts = [sharding.shard_frames(total, r, world)[1] for r in range(world)]
+            assert max(counts) - min(counts) <= 1
+
+
+def test_shard_mixed_buckets_by_code():
+    ids = np.array([1, 2] * 50 + [1] * 7)  # interleaved 1:1 stream plus a ragged tail (cfg 5)
+    world = 8
+    got = {1: [], 2: []}
+    for r in range(world):
+        for cid, idx in sharding.shard_mixed(ids, r, world).items():
+            assert np.all(ids[idx] == cid)
+            got[cid].extend(idx.tolist())
+    assert sorted(got[1]) == np.nonzero(ids == 1)[0].tolist()
+    assert sorted(got[2]) == np.nonzero(ids == 2)[0].tolist()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, total, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from ldpc_erasure_codes_amd import codes, synth
+    from oracle import oracle_py
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        code = codes.load_builtin(1)
+        oc = oracle_py.OracleCode(code)
+        f0, cnt = sharding.shard_frames(total, rank, world)
+        src = synth.source(5, f0, cnt, code.k, 1)[:, :, 0]
+        cw = np.stack([oc.encode(s) for s in src]) if cnt else np.zeros((0, code.n), np.uint8)
+        era = synth.erasures_uniform(6, f0, cnt, code.n, 0.2)
+        out, sw, res, st = oc.decode_batch_s1(cw, era)
+        words = torch.from_numpy(np.stack([sw, res, st]).astype(np.int32))
+        parts = sharding.gather_status(words)
+        t = sharding.max_over_ranks(0.5 + rank)
+        dist.barrier()
+        if rank == 0:
+            q.put((torch.cat(parts, dim=1).numpy(), t))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [10, 7])
+def test_world_size_2_gloo_shard_and_gather(total):
+    import torch.multiprocessing as mp
+    from ldpc_erasure_codes_amd import codes, synth
+    from oracle import oracle_py
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    gathered, tmax = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process decode of the whole batch must equal the gathered shards, in frame order
+    code = codes.load_builtin(1)
+    oc = oracle_py.OracleCode(code)
+    src = synth.source(5, 0, total, code.k, 1)[:, :, 0]
+    cw = np.stack([oc.encode(s) for s in src])
+    era = synth.erasures_uniform(6, 0, total, code.n, 0.2)
+    out, sw, res, st = oc.decode_batch_s1(cw, era)
+    assert np.array_equal(gathered, np.stack([sw, res, st]))
+    assert tmax == 1.5  # max over ranks of (0.5, 1.5)
