@@ -297,3 +297,26 @@ def test_rs_full_size_round_trip(oracle, n, k):
         keep = np.sort(rng.permutation(n)[: n - nerase])[:k].astype(np.uint16)
         msg, rc = oracle.rs_decode(G, keep, cw[keep])
         assert rc == 0 and np.array_equal(msg, src)
+
+
+# ---------------------------------------------------------------- synthesised (4080,3060) code (NOT the authors')
+def test_synthesised_code_c_structure(oracle):
+    """tools/hgen.cpp output: triangle form, no 4-cycles, degree profile close to
+    Matlab/Hgen_irregularDegree_no6cycles_systematic_encoding.m:38-40, and it encodes/decodes."""
+    import scipy.sparse as sp
+    c = codes.load_builtin(3)
+    assert (c.n, c.k, c.m) == (4080, 3060, 1020)
+    assert np.array_equal(c.cols[c.row_ptr[1:] - 1], c.k + np.arange(c.m))
+    rd = np.diff(c.row_ptr.astype(np.int64))
+    assert rd[-1] == 2 and set(np.unique(rd[:-1])) <= {13, 14, 15, 16}
+    assert np.bincount(c.cols, minlength=c.n).max() <= 16
+    H = sp.csr_matrix((np.ones(c.nnz, dtype=np.int32), c.cols.astype(np.int64), c.row_ptr.astype(np.int64)), shape=(c.m, c.n))
+    G = (H @ H.T).tolil()
+    G.setdiag(0)
+    assert G.tocsr().max() <= 1  # two checks never share two symbols: no 4-cycles
+    oc = oracle.OracleCode(c)
+    src = synth.source(3, 0, 2, c.k, 1)[:, :, 0]
+    cw = np.stack([oc.encode(s) for s in src])
+    era = synth.erasures_uniform(4, 0, 2, c.n, 0.12)
+    out, sw, res, st = oc.decode_batch_s1(cw, era)
+    assert np.array_equal(out, cw) and (st == 0).all()

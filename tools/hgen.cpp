@@ -1,0 +1,163 @@
+// hgen.cpp -- girth-8, lower-triangular ("triangle form") irregular LDPC parity-check matrix generator.
+//
+// Why it exists: BASELINE cfg 4 names a (4080,3060) code that the reference mentions
+// (Matlab/LDPCErasureCodes_MessagePassingAlgSim.m:42, profile at
+// Matlab/Hgen_irregularDegree_no6cycles_systematic_encoding.m:38-40) but does NOT ship.  This tool builds a
+// matrix of that shape with the same construction rules, from a fixed seed.  It is NOT the authors' matrix.
+//
+// Construction (behaviour of the reference's generator, Hgen_irregularDegree_...m:94-224, re-implemented):
+//   * rows are filled one at a time; row i takes (row degree - 1) columns among those left of the diagonal
+//     (col < k+i) that still have degree budget, drawn with probability proportional to (remaining budget)^3
+//     (:135,146), and then the diagonal column k+i (:189-194);
+//   * a candidate edge is rejected if it closes a 4-cycle or a 6-cycle in the graph built so far (:164-165);
+//   * the last row only gets its diagonal (:215), and every parity column left with degree 1 receives a
+//     "staircase" 1 just below its diagonal (:217-224) -- as in the reference this clean-up may create a few
+//     6-cycles;
+//   * when a row cannot be completed the column budgets are relaxed (up to +4) for that row, and if it still
+//     cannot be filled the row is kept lighter (the reference relaxes near the end, :113-115, and otherwise
+//     restarts the whole matrix; that is not needed for a usable code).
+// Output: the CSR fixture format of tools/export_reference_data.py ("LDPCCSR1").
+//
+//   g++ -O2 -std=c++17 -o /tmp/hgen tools/hgen.cpp
+//   /tmp/hgen 4080 3060 "682x15,338x14" "422x12,2638x3,964x2,56x1" 4080 ldpc_erasure_codes_amd/data/code_n4080_k3060.csr.bin
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+static uint64_t rng_state;
+static uint64_t next_u64()
+{  // SplitMix64
+    uint64_t x = (rng_state += 0x9E3779B97F4A7C15ull);
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+static double next_uniform() { return ((double)(next_u64() >> 11) + 0.5) * (1.0 / 9007199254740992.0); }
+
+static std::vector<int> parse_profile(const char *s)
+{
+    std::vector<int> out;
+    std::string str(s);
+    size_t pos = 0;
+    while (pos < str.size()) {
+        size_t comma = str.find(',', pos);
+        std::string tok = str.substr(pos, comma == std::string::npos ? std::string::npos : comma - pos);
+        int cnt = 0, deg = 0;
+        if (sscanf(tok.c_str(), "%dx%d", &cnt, &deg) != 2) { fprintf(stderr, "bad profile token %s\n", tok.c_str()); exit(1); }
+        for (int i = 0; i < cnt; i++) out.push_back(deg);
+        if (comma == std::string::npos) break;
+        pos = comma + 1;
+    }
+    return out;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 7) { fprintf(stderr, "usage: hgen n k rowprofile colprofile seed out.csr.bin\n"); return 1; }
+    const int n = atoi(argv[1]), k = atoi(argv[2]), m = n - k;
+    std::vector<int> rowdeg = parse_profile(argv[3]), tgt = parse_profile(argv[4]);
+    rng_state = strtoull(argv[5], nullptr, 10);
+    if ((int)rowdeg.size() != m || (int)tgt.size() != n) { fprintf(stderr, "profiles do not match (n,k)\n"); return 1; }
+
+    std::vector<std::vector<int>> rows(m), cols(n);
+    std::vector<int> cur(n, 0), mark(n, -1);
+    int stamp = 0, relaxed_rows = 0, short_rows = 0;
+
+    auto closes_short_cycle = [&](int i, int v) -> bool {
+        // columns already in row i
+        ++stamp;
+        for (int u : rows[i]) mark[u] = stamp;
+        for (int r1 : cols[v]) {
+            if (r1 == i) continue;
+            for (int u1 : rows[r1]) {
+                if (u1 == v) continue;
+                if (mark[u1] == stamp) return true;  // 4-cycle v-r1-u1-i
+                for (int r2 : cols[u1]) {
+                    if (r2 == r1 || r2 == i) continue;
+                    for (int u2 : rows[r2]) {
+                        if (u2 == u1 || u2 == v) continue;
+                        if (mark[u2] == stamp) return true;  // 6-cycle v-r1-u1-r2-u2-i
+                    }
+                }
+            }
+        }
+        return false;
+    };
+
+    for (int i = 0; i < m - 1; i++) {
+        const int want = rowdeg[i] - 1;
+        std::vector<char> tried(n, 0);
+        int relax = 0, got = 0;
+        while (got < want) {
+            std::vector<int> avail;
+            double total = 0;
+            for (int c = 0; c < k + i; c++) {
+                const int left = tgt[c] + relax - cur[c];
+                if (left > 0 && !tried[c]) { avail.push_back(c); total += (double)left * left * left; }
+            }
+            if (avail.empty()) {
+                if (relax >= 4) { short_rows++; break; }  // accept a lighter row rather than restarting (reference: restart)
+                relax++;
+                std::fill(tried.begin(), tried.end(), 0);
+                for (int u : rows[i]) tried[u] = 1;
+                if (relax == 1) relaxed_rows++;
+                continue;
+            }
+            const double value = total * next_uniform();
+            double cum = 0;
+            int pick = avail.back();
+            for (int c : avail) {
+                const int left = tgt[c] + relax - cur[c];
+                cum += (double)left * left * left;
+                if (cum >= value) { pick = c; break; }
+            }
+            tried[pick] = 1;
+            if (closes_short_cycle(i, pick)) continue;
+            rows[i].push_back(pick);
+            cols[pick].push_back(i);
+            cur[pick]++;
+            got++;
+        }
+        rows[i].push_back(k + i);  // triangle edge
+        cols[k + i].push_back(i);
+        cur[k + i]++;
+    }
+    rows[m - 1].push_back(n - 1);  // final triangle edge
+    cols[n - 1].push_back(m - 1);
+    int staircase = 0;
+    for (int c = k; c < n - 1; c++)
+        if ((int)cols[c].size() == 1) {  // degree-1 parity column: add the staircase 1 below the diagonal
+            const int r = c + 1 - k;
+            rows[r].push_back(c);
+            cols[c].push_back(r);
+            staircase++;
+        }
+
+    std::vector<uint32_t> row_ptr(m + 1, 0);
+    std::vector<uint16_t> cc;
+    int maxrow = 0, maxcol = 0;
+    for (int i = 0; i < m; i++) {
+        std::sort(rows[i].begin(), rows[i].end());
+        for (int c : rows[i]) cc.push_back((uint16_t)c);
+        row_ptr[i + 1] = (uint32_t)cc.size();
+        maxrow = std::max(maxrow, (int)rows[i].size());
+        if (rows[i].back() != k + i) { fprintf(stderr, "row %d is not in triangle form\n", i); return 3; }
+    }
+    for (int c = 0; c < n; c++) maxcol = std::max(maxcol, (int)cols[c].size());
+    FILE *f = fopen(argv[6], "wb");
+    if (!f) { perror("fopen"); return 4; }
+    const uint32_t hdr[4] = {(uint32_t)n, (uint32_t)k, (uint32_t)m, (uint32_t)cc.size()};
+    fwrite("LDPCCSR1", 1, 8, f);
+    fwrite(hdr, 4, 4, f);
+    fwrite(row_ptr.data(), 4, row_ptr.size(), f);
+    fwrite(cc.data(), 2, cc.size(), f);
+    fclose(f);
+    printf("n=%d k=%d m=%d nnz=%zu max row degree %d, max column degree %d, %d staircase ones, %d rows needed a relaxed budget, %d rows left lighter\n",
+           n, k, m, cc.size(), maxrow, maxcol, staircase, relaxed_rows, short_rows);
+    return 0;
+}
