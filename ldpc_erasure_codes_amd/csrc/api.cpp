@@ -202,11 +202,12 @@ static int register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_pt
     for (int e = 0; e < hc->nnz; e++)
         edges[e] = (uint32_t)cols[e] | ((uint32_t)hc->coefs[e] << 16) | ((uint32_t)gf.log[hc->coefs[e]] << 24);
     std::vector<uint16_t> ell_col((size_t)degpad * mpad, 0xFFFF);
-    std::vector<uint8_t> ell_logc((size_t)degpad * mpad, 0);
+    std::vector<uint8_t> ell_logc((size_t)degpad * mpad, 0), ell_coef((size_t)degpad * mpad, 0);
     for (int r = 0; r < m; r++)
         for (uint32_t e = row_ptr[r], t = 0; e < row_ptr[r + 1]; e++, t++) {
             ell_col[(size_t)t * mpad + r] = cols[e];
             ell_logc[(size_t)t * mpad + r] = gf.log[hc->coefs[e]];
+            ell_coef[(size_t)t * mpad + r] = hc->coefs[e];
         }
 
     // static encode schedule: row i solves column k+i (triangle form) once the parity symbols among its other
@@ -242,18 +243,26 @@ static int register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_pt
         }
     }
 
-    int maxcoldeg = 0;
+    int maxcoldeg = 0, cdw_shift = 0;
+    std::vector<uint32_t> cell;  // column lists: [n][maxcoldeg] check | coef << 16, 0xFFFFFFFF = none
     {
         std::vector<int> cdeg(n, 0);
         for (int e = 0; e < hc->nnz; e++) maxcoldeg = std::max(maxcoldeg, ++cdeg[cols[e]]);
+        while ((1 << cdw_shift) < maxcoldeg) cdw_shift++;
+        cell.assign((size_t)n << cdw_shift, 0xFFFFFFFFu);
+        std::fill(cdeg.begin(), cdeg.end(), 0);
+        for (int r = 0; r < m; r++)
+            for (uint32_t e = row_ptr[r]; e < row_ptr[r + 1]; e++)
+                cell[((size_t)cols[e] << cdw_shift) + cdeg[cols[e]]++] = (uint32_t)r | ((uint32_t)hc->coefs[e] << 16);
     }
     DevCode &d = hc->dev;
     d.n = n; d.k = k; d.m = m; d.nnz = hc->nnz; d.maxdeg = maxdeg; d.degpad = degpad; d.mpad = mpad;
-    d.maxcoldeg = maxcoldeg;
+    d.maxcoldeg = maxcoldeg; d.cdw_shift = cdw_shift;
     d.enc_nlevels = enc_nlevels;
     int rc;
     if ((rc = upload(ctx, hc, hc->row_ptr, &d.row_ptr)) || (rc = upload(ctx, hc, edges, &d.edges)) ||
         (rc = upload(ctx, hc, ell_col, &d.ell_col)) || (rc = upload(ctx, hc, ell_logc, &d.ell_logc)) ||
+        (rc = upload(ctx, hc, ell_coef, &d.ell_coef)) || (rc = upload(ctx, hc, cell, &d.cell)) ||
         (rc = upload(ctx, hc, enc_steps, &d.enc_steps)) || (rc = upload(ctx, hc, enc_lvlend, &d.enc_lvlend))) {
         free_code(hc);
         return rc;

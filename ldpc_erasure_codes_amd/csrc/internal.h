@@ -44,6 +44,9 @@ struct DevCode {
     const uint32_t *edges;    // [nnz]  col | coef << 16 | log(coef) << 24   (CSR order, ascending cols)
     const uint16_t *ell_col;  // [degpad][mpad]  transposed padded rows, 0xFFFF = none
     const uint8_t *ell_logc;  // [degpad][mpad]  log(coef)
+    const uint8_t *ell_coef;  // [degpad][mpad]  coef
+    const uint32_t *cell;     // [n][1 << cdw_shift]  column lists: check | coef << 16, 0xFFFFFFFF = none
+    int cdw_shift;            // log2 of the padded column-list width (>= maxcoldeg)
     // static encode schedule (all parity symbols erased): rows sorted by dependency level
     const uint32_t *enc_steps;   // [m] row | (k+row) << 16
     const uint16_t *enc_lvlend;  // [enc_nlevels+1], [L] = end offset of level L, [0] = 0

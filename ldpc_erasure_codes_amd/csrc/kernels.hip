@@ -37,6 +37,7 @@ namespace ldpc_amd {
 namespace {
 
 constexpr int kWave = 64;
+using us2 = unsigned short __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
@@ -51,6 +52,22 @@ __device__ __forceinline__ void wave_sync()
 }
 
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// Diagnostic build only (-DLDPC_AMD_STAMPS, tools/stamp_peel.py): per-phase cycle sums of the peel kernel go to a
+// buffer nothing else reads.  The product build contains no stamp.
+#ifdef LDPC_AMD_STAMPS
+__device__ unsigned long long g_peel_stamps[16];
+#define LDPC_STAMP(i)                                                                     \
+    do {                                                                                  \
+        const unsigned long long t__ = __builtin_amdgcn_s_memtime();                      \
+        if (lane_id() == 0) atomicAdd(&g_peel_stamps[i], t__ - stamp_prev);               \
+        stamp_prev = __builtin_amdgcn_s_memtime();                                        \
+    } while (0)
+#define LDPC_STAMP_INIT unsigned long long stamp_prev = __builtin_amdgcn_s_memtime()
+#else
+#define LDPC_STAMP(i) do { } while (0)
+#define LDPC_STAMP_INIT do { } while (0)
+#endif
 
 // =================================================================================================
 // a1: peeling of one frame by one wavefront -- exact in-order (Gauss-Seidel) sweep semantics
@@ -76,17 +93,23 @@ __device__ __forceinline__ void peel_wave(const uint16_t *ell_col, int mpad, uin
         sweeps++;                               // :23
         for (int ch = 0; ch < nchunks && remaining > 0; ch++) {  // :27 (rows past the last erasure change nothing)
             const int row = (ch << 6) + lane;
-            uint32_t c[MAXDEG];
+            // two rounds of independent LDS reads: the check's neighbour ids, then their states
+            uint32_t c[MAXDEG], sv[MAXDEG];
+#pragma unroll
+            for (int t = 0; t < MAXDEG; t++) c[t] = ell_col[t * mpad + row];
+#pragma unroll
+            for (int t = 0; t < MAXDEG; t++) sv[t] = st[c[t] == 0xFFFFu ? 0u : c[t]];
             int cnt = 0;
             uint32_t xs = 0, ml = 0;
+            us2 cp[MAXDEG / 2];  // neighbour ids packed in pairs for the membership test below (0xFFFF = none)
 #pragma unroll
             for (int t = 0; t < MAXDEG; t++) {  // :30-35
-                c[t] = ell_col[t * mpad + row];
-                if (c[t] != 0xFFFFu) {
-                    const uint32_t s = st[c[t]];
-                    if (s == 0xFFFFu) { cnt++; xs ^= c[t]; }
-                    else ml = max(ml, s);
-                }
+                const bool valid = c[t] != 0xFFFFu;
+                const bool er = valid && sv[t] == 0xFFFFu;
+                cnt += er ? 1 : 0;
+                xs ^= er ? c[t] : 0u;
+                ml = max(ml, (valid && !er) ? sv[t] : 0u);
+                if (t & 1) cp[t >> 1] = us2{(unsigned short)c[t - 1], (unsigned short)c[t]};
             }
             uint64_t elig = ~0ull;
             for (;;) {
@@ -103,9 +126,12 @@ __device__ __forceinline__ void peel_wave(const uint16_t *ell_col, int mpad, uin
                 nsteps++; remaining--;
                 maxlvl = max(maxlvl, (int)lv);
                 elig = (l == 63) ? 0ull : (~0ull << (l + 1));
-                bool hit = false;
+                // does this check contain e?  min over (id ^ e) of the packed pairs is 0 in the matching half
+                const us2 ee = us2{(unsigned short)e, (unsigned short)e};
+                us2 mn = us2{(unsigned short)0xFFFFu, (unsigned short)0xFFFFu};
 #pragma unroll
-                for (int t = 0; t < MAXDEG; t++) hit |= (c[t] == e);
+                for (int t = 0; t < MAXDEG / 2; t++) mn = __builtin_elementwise_min(mn, (us2)(cp[t] ^ ee));
+                const bool hit = (mn.x == 0) || (mn.y == 0);
                 if (hit && lane > l) { cnt--; xs ^= e; ml = max(ml, lv); }
                 if (lane == l) cnt = 0;
             }
@@ -161,7 +187,6 @@ struct PeelLds {        // byte offsets into dynamic LDS
     int steps;          // u32 [m]
     int slvl;           // u16 [m]
     int sorted;         // u32 [m]
-    int cnt;            // u32 [n]  per-source edge counters       (packet path only)
     int total;
 };
 
@@ -180,11 +205,10 @@ struct PeelArgs {
     uint32_t *sched_hdr;    // [nframes][2]  nsteps, maxlvl
     uint32_t *sched_steps;  // [nframes][m]
     uint16_t *sched_lvlend; // [nframes][m+1]
-    // packet path, scatter form: for every source symbol j the (slot, coefficient) pairs of the steps it feeds
     int32_t *big_list;      // [0] = count, [1..] frames with more than tcap steps (scatter tier 2), or nullptr
     int tcap;
-    uint8_t *src_cnt;       // [nframes][n]              number of pairs of symbol j  (or nullptr)
-    uint32_t *src_pad;      // [nframes][n][maxcoldeg]   slot | coef << 16, first src_cnt entries valid
+    // packet path, scatter form: for every source symbol j the (slot, coefficient) pairs of the steps it feeds
+    uint32_t *src_pad;      // [nframes][n][1 << cdw_shift]   slot | coef << 16, or 0xFFFFFFFF   (or nullptr)
     // ML hand-off
     int32_t *ml_list;       // [0] = count, [1..] frame ids
     uint8_t *ml_state;      // [slot][n]  1 = still erased
@@ -222,6 +246,7 @@ __global__ __launch_bounds__(256) void ldpc_peel_kernel(PeelArgs a)
 
     const int64_t f = (int64_t)blockIdx.x * wpb + wave;
     if (f >= a.nframes) return;  // no workgroup barrier below this point
+    LDPC_STAMP_INIT;
 
     unsigned char *wbase = smem + a.lds.wave0 + wave * a.lds.wave_stride;
     uint16_t *st = reinterpret_cast<uint16_t *>(wbase + a.lds.st);
@@ -235,21 +260,62 @@ __global__ __launch_bounds__(256) void ldpc_peel_kernel(PeelArgs a)
     {
         const uint8_t *er = a.erased ? a.erased + f * n : nullptr;
         const uint8_t *sy = FUSED_S1 ? a.sym + f * a.in_rows : nullptr;
-        for (int j0 = 0; j0 < n; j0 += kWave) {
-            const int j = j0 + lane;
-            bool e = false;
-            if (j < n) {
-                e = er ? (er[j] != 0) : (j >= a.in_rows);
-                st[j] = e ? (uint16_t)0xFFFFu : (uint16_t)0;
-                if (FUSED_S1) y[j] = (e || j >= a.in_rows) ? (uint8_t)0 : sy[j];
+        const bool fast = ((n & 7) == 0) && ((a.in_rows & 7) == 0) && ((reinterpret_cast<uintptr_t>(er) & 7) == 0) &&
+                          ((reinterpret_cast<uintptr_t>(sy) & 7) == 0);
+        if (fast) {
+            // 8 flags (and 8 symbols) per 64-bit load, 4 independent loads in flight per lane
+            constexpr int U = 4;
+            const int nq = n >> 3;
+            const uint64_t *er64 = reinterpret_cast<const uint64_t *>(er);
+            const uint64_t *sy64 = reinterpret_cast<const uint64_t *>(sy);
+            int cnt = 0;
+            for (int q0 = 0; q0 < nq; q0 += kWave * U) {
+                uint64_t ew[U], sw[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int q = q0 + u * kWave + lane;
+                    ew[u] = (er && q < nq) ? er64[q] : 0ull;
+                    sw[u] = (FUSED_S1 && q < nq && q * 8 < a.in_rows) ? sy64[q] : 0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const int q = q0 + u * kWave + lane;
+                    if (q < nq) {
+                        uint32_t s4[4] = {0, 0, 0, 0};
+                        uint64_t yv = 0;
+#pragma unroll
+                        for (int b = 0; b < 8; b++) {
+                            const bool e = er ? (((ew[u] >> (8 * b)) & 0xFFull) != 0) : (q * 8 + b >= a.in_rows);
+                            if (e) { s4[b >> 1] |= 0xFFFFu << (16 * (b & 1)); cnt++; }
+                            else yv |= ((sw[u] >> (8 * b)) & 0xFFull) << (8 * b);
+                        }
+                        *reinterpret_cast<U4 *>(st + q * 8) = U4{s4[0], s4[1], s4[2], s4[3]};
+                        if (FUSED_S1) *reinterpret_cast<uint64_t *>(y + q * 8) = yv;
+                    }
+                }
             }
-            remaining += __popcll(__ballot(e));
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) cnt += __shfl_xor(cnt, d);
+            remaining = cnt;
+        } else {
+            for (int j0 = 0; j0 < n; j0 += kWave) {
+                const int j = j0 + lane;
+                bool e = false;
+                if (j < n) {
+                    e = er ? (er[j] != 0) : (j >= a.in_rows);
+                    st[j] = e ? (uint16_t)0xFFFFu : (uint16_t)0;
+                    if (FUSED_S1) y[j] = (e || j >= a.in_rows) ? (uint8_t)0 : sy[j];
+                }
+                remaining += __popcll(__ballot(e));
+            }
         }
     }
     wave_sync();
 
+    LDPC_STAMP(0);  // frame load
     int nsteps, sweeps, maxlvl;
     peel_wave<MAXDEG>(ell_col, mpad, st, steps, slvl, a.max_sweeps, nsteps, remaining, sweeps, maxlvl);
+    LDPC_STAMP(1);  // peeling sweeps
 
     // ---- per-frame results + hand-off of residual frames to the ML stage
     int stcode = LDPC_AMD_ST_MP_DONE;
@@ -283,7 +349,9 @@ __global__ __launch_bounds__(256) void ldpc_peel_kernel(PeelArgs a)
 
     // ---- group the steps by dependency level (st is dead from here on: reuse it for the level offsets)
     uint32_t *lvlend = reinterpret_cast<uint32_t *>(st);
+    LDPC_STAMP(2);  // status words / ML hand-off
     sort_steps_by_level(steps, slvl, nsteps, maxlvl, lvlend, sorted);
+    LDPC_STAMP(3);  // level sort
 
     if (!FUSED_S1) {
         if (!a.sched_hdr) return;  // flags-only run
@@ -296,34 +364,45 @@ __global__ __launch_bounds__(256) void ldpc_peel_kernel(PeelArgs a)
         for (int i = lane; i < nsteps; i += kWave) gs[i] = sorted[i];
         uint16_t *gl = a.sched_lvlend + f * (m + 1);
         for (int i = lane; i <= maxlvl; i += kWave) gl[i] = (uint16_t)lvlend[i];
-        if (!a.src_cnt) return;
-        // Transpose the used checks: symbol j -> list of (slot of the step it feeds, H(row, j)).  The slot is
-        // the step's position in level order.  Every neighbour of a used check except its target is a source.
-        // four 8-bit counters per LDS word (a symbol feeds at most maxcoldeg <= 16 steps)
-        uint32_t *cnt = reinterpret_cast<uint32_t *>(wbase + a.lds.cnt);
-        for (int j = lane; j < (n + 3) / 4; j += kWave) cnt[j] = 0;
+        LDPC_STAMP(4);  // schedule write-out
+        if (!a.src_pad) return;
+        // Transpose the used checks: symbol j -> (slot of the step it feeds, H(check, j)) for every USED check that
+        // contains j, except the check that solves j itself.  Lane = symbol: H's static column lists are read
+        // coalesced from L2, the check -> slot table sits in LDS, and each lane writes its own contiguous run.
+        uint16_t *soc = slvl;  // slvl is dead after the sort: reuse it as check -> slot (0xFFFF = unused)
+        for (int i = lane; i < m; i += kWave) soc[i] = 0xFFFFu;
         wave_sync();
-        const int cdw = cd.maxcoldeg;
-        uint32_t *gp = a.src_pad + f * (int64_t)n * cdw;
-        for (int s = lane; s < nsteps; s += kWave) {
-            const uint32_t step = sorted[s];
-            const int row = (int)(step & 0xFFFFu);
-            const uint32_t tgt = step >> 16;
-            const uint32_t e0 = cd.row_ptr[row];
+        for (int s = lane; s < nsteps; s += kWave) soc[sorted[s] & 0xFFFFu] = (uint16_t)s;
+        wave_sync();
+        // One lane per entry of H's column lists (padded to cdwp = 2^sh entries per symbol): coalesced 256-byte
+        // reads and writes; unused entries become 0xFFFFFFFF and are skipped by the scatter kernel.
+        const int sh = cd.cdw_shift, cdwp = 1 << sh;
+        const uint32_t *cellp = cd.cell;
+        uint32_t *gp = a.src_pad + f * (int64_t)n * cdwp;
+        const int words = n << sh;
+        // Batches of 16 entries per lane, each step done for the whole batch before the next one (independent L2
+        // loads, then independent LDS reads) -- per-entry dependent chains made this loop latency bound.
+        constexpr int U = 16;
+        for (int w0 = 0; w0 < words; w0 += kWave * U) {
+            uint32_t ce[U], sl[U], tg[U];
 #pragma unroll
-            for (int t = 0; t < MAXDEG; t++) {
-                const uint32_t c = ell_col[t * mpad + row];
-                if (c != 0xFFFFu && c != tgt) {
-                    const uint32_t coef = (cd.edges[e0 + t] >> 16) & 0xFFu;
-                    const uint32_t sh = 8u * (c & 3u);
-                    const uint32_t pos = (atomicAdd(&cnt[c >> 2], 1u << sh) >> sh) & 0xFFu;
-                    gp[(int64_t)c * cdw + pos] = (uint32_t)s | (coef << 16);
-                }
+            for (int u = 0; u < U; u++) {
+                const int w = w0 + u * kWave + lane;
+                ce[u] = (w < words) ? cellp[w] : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) sl[u] = soc[ce[u] == 0xFFFFFFFFu ? 0u : (ce[u] & 0xFFFFu)];
+#pragma unroll
+            for (int u = 0; u < U; u++) tg[u] = sorted[sl[u] == 0xFFFFu ? 0u : sl[u]] >> 16;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int w = w0 + u * kWave + lane;
+                const bool valid = (ce[u] != 0xFFFFFFFFu) && (sl[u] != 0xFFFFu) && (tg[u] != (uint32_t)(w >> sh));
+                // whole 256-byte lines are written (pad = 0xFFFFFFFF): partial-line stores were store-issue bound
+                if (w < words) gp[w] = valid ? (sl[u] | (ce[u] & 0x00FF0000u)) : 0xFFFFFFFFu;
             }
         }
-        wave_sync();
-        uint8_t *gc = a.src_cnt + f * (int64_t)n;
-        for (int j = lane; j < n; j += kWave) gc[j] = reinterpret_cast<const uint8_t *>(cnt)[j];
+        LDPC_STAMP(5);  // per-source lists
         return;
     }
 
@@ -337,18 +416,20 @@ __global__ __launch_bounds__(256) void ldpc_peel_kernel(PeelArgs a)
                 const uint32_t step = sorted[i];
                 const int row = (int)(step & 0xFFFFu);
                 const uint32_t tgt = step >> 16;
+                // four rounds of independent LDS reads instead of MAXDEG dependent chains
+                uint32_t c[MAXDEG], lc[MAXDEG], v[MAXDEG], lv[MAXDEG];
+#pragma unroll
+                for (int t = 0; t < MAXDEG; t++) { c[t] = ell_col[t * mpad + row]; lc[t] = ell_logc[t * mpad + row]; }
+#pragma unroll
+                for (int t = 0; t < MAXDEG; t++) v[t] = y[c[t] == 0xFFFFu ? 0u : c[t]];
+#pragma unroll
+                for (int t = 0; t < MAXDEG; t++) lv[t] = lg[v[t]];
                 uint32_t sum = 0, lce = 0;
 #pragma unroll
                 for (int t = 0; t < MAXDEG; t++) {
-                    const uint32_t c = ell_col[t * mpad + row];
-                    if (c != 0xFFFFu) {
-                        const uint32_t lc = ell_logc[t * mpad + row];
-                        if (c == tgt) lce = lc;
-                        else {
-                            const uint32_t v = y[c];
-                            if (v) sum ^= ex[lg[v] + lc];
-                        }
-                    }
+                    const uint32_t p = ex[lv[t] + lc[t]];
+                    if (c[t] == tgt) lce = lc[t];
+                    else if (c[t] != 0xFFFFu && v[t]) sum ^= p;
                 }
                 y[tgt] = sum ? ex[lg[sum] + 255u - lce] : (uint8_t)0;
             }
@@ -356,6 +437,7 @@ __global__ __launch_bounds__(256) void ldpc_peel_kernel(PeelArgs a)
         }
     }
 
+    LDPC_STAMP(6);  // S = 1 apply
     // ---- write Msg (...Decoder.m:129); unknown symbols are 0
     uint8_t *o = a.out + f * n;
     if ((n & 3) == 0) {
@@ -365,6 +447,7 @@ __global__ __launch_bounds__(256) void ldpc_peel_kernel(PeelArgs a)
     } else {
         for (int j = lane; j < n; j += kWave) o[j] = y[j];
     }
+    LDPC_STAMP(7);  // output store
 }
 
 // =================================================================================================
@@ -467,7 +550,7 @@ __global__ __launch_bounds__(512) void ldpc_apply_kernel(ApplyArgs a)
 // copy, ~1.3 times as a source) and the fetches are too far apart in time to hit in L2 / Infinity Cache.
 // Here every received row is read from HBM exactly ONCE: it is written to `out` and, while still in
 // registers, multiplied into the accumulators of the steps it feeds (the per-frame transposed lists the peel
-// kernel emits).  The accumulators of all steps of the frame slice live in LDS (T x B bytes, B = 16*LPR
+// kernel emits; a variant that walked H's static column lists inside this kernel instead measured 25 % slower).  The accumulators of all steps of the frame slice live in LDS (T x B bytes, B = 16*LPR
 // bytes of every row per workgroup; 4 slices x 256 B for S = 1024 on the (2040,1530) code = 130 KB), updated
 // with ds_xor_b64.  HBM traffic per frame: 0.9 nS read + nS write -- the algorithmic minimum for an
 // out-of-place decode.  Solved symbols are finalised level by level (acc * inv(h)), written out and scattered
@@ -486,11 +569,10 @@ struct ScatterArgs {
     const uint32_t *sched_hdr;
     const uint32_t *sched_steps;
     const uint16_t *sched_lvlend;
-    const uint8_t *src_cnt;
     const uint32_t *src_pad;
     int tcap;                 // tier 1 handles frames with at most tcap steps (its LDS holds tcap accumulators)
     const int32_t *big_list;  // tier 2: [0] = count, [1..] ids of the frames with more steps; nullptr in tier 1
-    int lds_acc, lds_tgt, lds_invc, lds_lvlend, lds_solved, lds_mt;
+    int lds_acc, lds_tgt, lds_invc, lds_lvlend, lds_solved, lds_mt, lds_soc;
 };
 
 __device__ __forceinline__ MulTab lds_multab(const uint32_t *mt, uint32_t c)
@@ -556,6 +638,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     uint16_t *lvlend = reinterpret_cast<uint16_t *>(smem + a.lds_lvlend);
     uint32_t *solved = reinterpret_cast<uint32_t *>(smem + a.lds_solved);
     uint32_t *mt = reinterpret_cast<uint32_t *>(smem + a.lds_mt);
+    uint8_t *rk = smem + a.lds_soc;  // row kinds, [n]
 
     const int nsteps = (int)a.sched_hdr[2 * f], nlev = (int)a.sched_hdr[2 * f + 1];
     const uint32_t *gs = a.sched_steps + f * cd.m;
@@ -578,23 +661,30 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         atomicOr(&solved[t >> 5], 1u << (t & 31));
     }
     __syncthreads();
+    {   // row kinds: 1 received, 2 erased and never solved (written as 0), 0 erased and solved in phase B
+        const uint8_t *erf = a.erased + f * (int64_t)n;
+        for (int j = tid; j < n; j += nthr)
+            rk[j] = erf[j] ? (((solved[j >> 5] >> (j & 31)) & 1u) ? (uint8_t)0 : (uint8_t)2) : (uint8_t)1;
+    }
+    __syncthreads();
 
     const uint8_t *fin = a.sym + f * (int64_t)n * S + (int64_t)sl * B + gl * 16;
     uint8_t *fout = a.out + f * (int64_t)n * S + (int64_t)sl * B + gl * 16;
-    const uint8_t *er = a.erased + f * (int64_t)n;
-    const uint8_t *scnt = a.src_cnt + f * (int64_t)n;
-    const uint32_t *spad = a.src_pad + f * (int64_t)n * cdw;
+    const uint32_t *spad = a.src_pad + ((f * (int64_t)n) << cd.cdw_shift);
 
-    // multiplies v into the accumulators of the steps that symbol j feeds (cn pairs, KQ words per lane)
-    auto scatter = [&](const U4 &v, int cn, const uint32_t (&ew)[KQ]) {
+    // multiplies v into the accumulators of the steps that symbol j feeds: ew = the symbol's list, entry t held by
+    // lane (t % LPR) of the group, 0xFFFFFFFF = no entry.  Every group walks the set bits of its own validity mask.
+    auto scatter = [&](const U4 &v, const uint32_t (&ew)[KQ]) {
 #pragma unroll
         for (int q = 0; q < KQ; q++) {
-            if (!__any(q * LPR < cn)) break;
-            for (int u = 0; u < LPR; u++) {
-                const int t = q * LPR + u;
-                if (!__any(t < cn)) break;
+            if (q * LPR >= cdw) break;
+            uint32_t gm = (uint32_t)(__ballot(ew[q] != 0xFFFFFFFFu) >> gbase) & (uint32_t)((1ull << LPR) - 1ull);
+            while (__any(gm != 0)) {
+                const bool go = gm != 0;
+                const int u = go ? (__ffs((int)gm) - 1) : 0;
+                gm &= gm - 1u;
                 const uint32_t ed = (uint32_t)__shfl((int)ew[q], gbase + u);
-                if (t < cn) {
+                if (go) {
                     const uint32_t s = ed & 0xFFFFu, c = (ed >> 16) & 0xFFu;
                     const U4 prod = gfmul16(lds_multab(mt, c), v);
                     lds_xor16(acc + (size_t)s * B + gl * 16, prod, h);
@@ -603,39 +693,47 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         }
     };
 
-    // ---- phase A: stream the received rows once
-    for (int j0 = wave * R * RPW; j0 < n; j0 += nw * R * RPW) {
+    // ---- phase A: stream the received rows once.  Software pipelined: batch i+1's loads are issued before batch
+    //      i's stores (vmcnt retires in order and counts stores -- loads issued behind stores would wait for them),
+    //      and the row kinds come from LDS so that no global load sits between a wave and its row loads.
+    struct RowBatch {
         U4 v[R];
         uint32_t ew[R][KQ];
-        int cn[R];
-        int kind[R];  // 0 nothing, 1 received row, 2 erased and never solved (written as 0)
+        int kind[R];  // 0 skip (erased and solved later, or past the end), 1 received row, 2 erased and never solved
+    };
+    auto fetch = [&](int j0, RowBatch &b) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int j = j0 + r * RPW + g;
-            kind[r] = 0; cn[r] = 0;
-            v[r] = U4{0, 0, 0, 0};
+            const int kd = (j < n) ? (int)rk[j] : 0;
+            b.kind[r] = kd;
+            b.v[r] = U4{0, 0, 0, 0};
 #pragma unroll
-            for (int q = 0; q < KQ; q++) ew[r][q] = 0;
-            if (j < n) {
-                if (!er[j]) {
-                    kind[r] = 1;
-                    v[r] = stream_load16<NT>(fin + (int64_t)j * S);
-                    cn[r] = scnt[j];
+            for (int q = 0; q < KQ; q++) b.ew[r][q] = 0xFFFFFFFFu;
+            if (kd == 1) {
+                b.v[r] = stream_load16<NT>(fin + (int64_t)j * S);
 #pragma unroll
-                    for (int q = 0; q < KQ; q++) {
-                        const int idx = gl + q * LPR;
-                        if (idx < cdw) ew[r][q] = spad[(int64_t)j * cdw + idx];
-                    }
-                } else if (!((solved[j >> 5] >> (j & 31)) & 1u)) {
-                    kind[r] = 2;
+                for (int q = 0; q < KQ; q++) {
+                    const int idx = gl + q * LPR;
+                    if (idx < cdw) b.ew[r][q] = spad[((int64_t)j << cd.cdw_shift) + idx];
                 }
             }
         }
+    };
+    {
+        const int stride = nw * R * RPW;
+        RowBatch cur, nxt;
+        int j0 = wave * R * RPW;
+        fetch(j0, cur);
+        for (; j0 < n; j0 += stride) {
+            fetch(j0 + stride, nxt);
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int j = j0 + r * RPW + g;
-            if (kind[r]) stream_store16<NT>(fout + (int64_t)j * S, v[r]);
-            scatter(v[r], cn[r], ew[r]);
+            for (int r = 0; r < R; r++) {
+                const int j = j0 + r * RPW + g;
+                if (cur.kind[r]) stream_store16<NT>(fout + (int64_t)j * S, cur.v[r]);
+                scatter(cur.v[r], cur.ew[r]);
+            }
+            cur = nxt;
         }
     }
     __syncthreads();
@@ -647,22 +745,20 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
             const int s = sb + g;
             U4 val = {0, 0, 0, 0};
             uint32_t ew[KQ];
-            int cn = 0;
 #pragma unroll
-            for (int q = 0; q < KQ; q++) ew[q] = 0;
+            for (int q = 0; q < KQ; q++) ew[q] = 0xFFFFFFFFu;
             if (s < s1) {
                 const int t = tgt[s];
                 const U4 a16 = *reinterpret_cast<const U4 *>(acc + (size_t)s * B + gl * 16);
                 val = gfmul16(lds_multab(mt, invc[s]), a16);
                 stream_store16<NT>(fout + (int64_t)t * S, val);
-                cn = scnt[t];
 #pragma unroll
                 for (int q = 0; q < KQ; q++) {
                     const int idx = gl + q * LPR;
-                    if (idx < cdw) ew[q] = spad[(int64_t)t * cdw + idx];
+                    if (idx < cdw) ew[q] = spad[((int64_t)t << cd.cdw_shift) + idx];
                 }
             }
-            scatter(val, cn, ew);
+            scatter(val, ew);
         }
         __syncthreads();
     }
@@ -962,7 +1058,7 @@ hipError_t upload_constants(hipStream_t s)
 
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
-static PeelLds make_peel_lds(const DevCode &cd, bool fused, int wpb, bool srclists = false)
+static PeelLds make_peel_lds(const DevCode &cd, bool fused, int wpb)
 {
     PeelLds L{};
     int off = 0;
@@ -977,7 +1073,6 @@ static PeelLds make_peel_lds(const DevCode &cd, bool fused, int wpb, bool srclis
     L.steps = w; w += align_up(4 * cd.m, 16);
     L.slvl = w; w += align_up(2 * cd.m, 16);
     L.sorted = w; w += align_up(4 * cd.m, 16);
-    L.cnt = w; if (srclists) w += align_up(cd.n + 4, 16);
     L.wave_stride = w;
     L.total = off + wpb * w;
     return L;
@@ -1016,7 +1111,7 @@ struct ScatterPlan {
     int tcap = 0;       // tier 1 handles frames with <= tcap steps
     bool two_tier = false;
     int lds1 = 0, lds2 = 0;                       // dynamic LDS bytes of tier 1 / tier 2
-    int o_tgt = 0, o_invc = 0, o_lvl = 0, o_sol = 0, o_mt = 0;  // offsets behind the accumulators (relative)
+    int o_tgt = 0, o_invc = 0, o_lvl = 0, o_sol = 0, o_mt = 0, o_soc = 0;  // offsets behind the accumulators (relative)
 };
 
 static int scatter_tail_bytes(const DevCode &cd, ScatterPlan &p)
@@ -1027,6 +1122,7 @@ static int scatter_tail_bytes(const DevCode &cd, ScatterPlan &p)
     p.o_lvl = off; off += align_up(2 * (cd.m + 2), 16);
     p.o_sol = off; off += align_up((cd.n + 31) / 32 * 4, 16);
     p.o_mt = off; off += 8192;
+    p.o_soc = off; off += align_up(cd.n, 16);  // row kinds
     return off;
 }
 
@@ -1063,13 +1159,12 @@ static void scatter_set_lds(ScatterArgs &sa, const ScatterPlan &p, int nacc)
     const int base = align_up(nacc * 16 * p.lpr, 16);
     sa.lds_acc = 0;
     sa.lds_tgt = base + p.o_tgt; sa.lds_invc = base + p.o_invc; sa.lds_lvlend = base + p.o_lvl;
-    sa.lds_solved = base + p.o_sol; sa.lds_mt = base + p.o_mt;
+    sa.lds_solved = base + p.o_sol; sa.lds_mt = base + p.o_mt; sa.lds_soc = base + p.o_soc;
 }
 
-template <int LPR>
+template <int LPR, int R>
 static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterArgs sa, const int32_t *big_list)
 {
-    constexpr int R = (LPR >= 8) ? 4 : 1;
     constexpr int THREADS = (LPR >= 8) ? 1024 : (LPR >= 2 ? 512 : 256);
     const char *env_nt = getenv("LDPC_AMD_SCATTER_NT");
     const bool nt = env_nt ? atoi(env_nt) != 0 : true;
@@ -1108,12 +1203,14 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
 
 static int launch_scatter(ldpc_amd_ctx *ctx, const ScatterPlan &p, const ScatterArgs &sa, const int32_t *big_list)
 {
+    const char *env_r = getenv("LDPC_AMD_SCATTER_R");
+    const int rr = env_r ? atoi(env_r) : 2;
     switch (p.lpr) {
-        case 16: return launch_scatter_lpr<16>(ctx, p, sa, big_list);
-        case 8: return launch_scatter_lpr<8>(ctx, p, sa, big_list);
-        case 4: return launch_scatter_lpr<4>(ctx, p, sa, big_list);
-        case 2: return launch_scatter_lpr<2>(ctx, p, sa, big_list);
-        case 1: return launch_scatter_lpr<1>(ctx, p, sa, big_list);
+        case 16: return rr == 4 ? launch_scatter_lpr<16, 4>(ctx, p, sa, big_list) : (rr == 1 ? launch_scatter_lpr<16, 1>(ctx, p, sa, big_list) : launch_scatter_lpr<16, 2>(ctx, p, sa, big_list));
+        case 8: return rr == 4 ? launch_scatter_lpr<8, 4>(ctx, p, sa, big_list) : launch_scatter_lpr<8, 2>(ctx, p, sa, big_list);
+        case 4: return launch_scatter_lpr<4, 1>(ctx, p, sa, big_list);
+        case 2: return launch_scatter_lpr<2, 1>(ctx, p, sa, big_list);
+        case 1: return launch_scatter_lpr<1, 1>(ctx, p, sa, big_list);
     }
     return set_error(ctx, LDPC_AMD_EUNSUP, "scatter: bad plan");
 }
@@ -1155,8 +1252,8 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
 
     // workgroup shape: as many frames per workgroup as fit comfortably in LDS
     int wpb = 4;
-    PeelLds L = make_peel_lds(cd, fused, wpb, use_scatter);
-    while (wpb > 1 && L.total > 96 * 1024) { wpb >>= 1; L = make_peel_lds(cd, fused, wpb, use_scatter); }
+    PeelLds L = make_peel_lds(cd, fused, wpb);
+    while (wpb > 1 && L.total > 96 * 1024) { wpb >>= 1; L = make_peel_lds(cd, fused, wpb); }
     if (L.total > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "code too large for LDS (%d bytes)", L.total);
 
     const int64_t nf = d.nframes;
@@ -1187,13 +1284,12 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         const size_t hdr = (size_t)nf * 2 * 4, st = (size_t)nf * cd.m * 4, le = (size_t)nf * (cd.m + 1) * 2;
         const size_t o1 = (hdr + 255) & ~(size_t)255, o2 = (o1 + st + 255) & ~(size_t)255;
         const size_t o3 = (o2 + le + 255) & ~(size_t)255;
-        const size_t sc = use_scatter ? (size_t)nf * cd.n : 0, sp = use_scatter ? (size_t)nf * cd.n * cd.maxcoldeg * 4 : 0;
-        const size_t o4 = (o3 + sc + 255) & ~(size_t)255;
-        if ((rc = scratch_reserve(ctx, ctx->sched, o4 + sp))) return rc;
+        const size_t sp = use_scatter ? ((size_t)nf * cd.n * 4) << cd.cdw_shift : 0;
+        if ((rc = scratch_reserve(ctx, ctx->sched, o3 + sp))) return rc;
         unsigned char *base = (unsigned char *)ctx->sched.p;
         pa.sched_hdr = (uint32_t *)base; pa.sched_steps = (uint32_t *)(base + o1); pa.sched_lvlend = (uint16_t *)(base + o2);
         if (use_scatter) {
-            pa.src_cnt = base + o3; pa.src_pad = (uint32_t *)(base + o4);
+            pa.src_pad = (uint32_t *)(base + o3);
             pa.tcap = plan.tcap;
             pa.big_list = plan.two_tier ? (int32_t *)ctx->biglist.p : nullptr;
         }
@@ -1205,7 +1301,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             ScatterArgs sa{};
             sa.code = cd; sa.S = d.S; sa.nslices = plan.nslices; sa.nframes = nf; sa.sym = d.sym; sa.erased = d.erased; sa.out = d.out;
             sa.sched_hdr = pa.sched_hdr; sa.sched_steps = pa.sched_steps; sa.sched_lvlend = pa.sched_lvlend;
-            sa.src_cnt = pa.src_cnt; sa.src_pad = pa.src_pad;
+            sa.src_pad = pa.src_pad;
             ev = prof_begin(ctx);
             if ((rc = launch_scatter(ctx, plan, sa, (const int32_t *)ctx->biglist.p))) return rc;
             prof_end(ctx, LDPC_AMD_PROF_APPLY, ev);
@@ -1324,6 +1420,19 @@ int launch_fpga_stats(ldpc_amd_ctx *ctx, const DevCode &code, int rs_n, int rs_k
     LDPC_HIP_TRY(ctx, hipGetLastError());
     return LDPC_AMD_OK;
 }
+
+#ifdef LDPC_AMD_STAMPS
+extern "C" int ldpc_amd_debug_peel_stamps(ldpc_amd_ctx *ctx, unsigned long long *out16, int reset)
+{
+    LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    LDPC_HIP_TRY(ctx, hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_peel_stamps), 16 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        LDPC_HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_peel_stamps), z, sizeof(z)));
+    }
+    return LDPC_AMD_OK;
+}
+#endif
 
 int launch_selftest(ldpc_amd_ctx *ctx)
 {

@@ -50,10 +50,13 @@ def main():
         "scatter 1tier nt": {"LDPC_AMD_SCATTER_TIERS": "1", "LDPC_AMD_SCATTER_NT": "1"},
         "scatter 2tier": {"LDPC_AMD_SCATTER_NT": "0"},
         "scatter 2tier nt": {"LDPC_AMD_SCATTER_NT": "1"},
+        "scatter 2tier nt R1": {"LDPC_AMD_SCATTER_NT": "1", "LDPC_AMD_SCATTER_R": "1"},
+        "scatter 2tier nt R2": {"LDPC_AMD_SCATTER_NT": "1", "LDPC_AMD_SCATTER_R": "2"},
+        "scatter 2tier nt R4": {"LDPC_AMD_SCATTER_NT": "1", "LDPC_AMD_SCATTER_R": "4"},
     }
     if args.variants:
         variants = {k: v for k, v in variants.items() if any(x in k for x in args.variants.split(","))}
-    knobs = ["LDPC_AMD_APPLY", "LDPC_AMD_SCATTER_TIERS", "LDPC_AMD_SCATTER_NT"]
+    knobs = ["LDPC_AMD_APPLY", "LDPC_AMD_SCATTER_TIERS", "LDPC_AMD_SCATTER_NT", "LDPC_AMD_SCATTER_R"]
     times = {name: {"peel": [], "apply": []} for name in variants}
     ctx.set_profiling(True)
     for rnd in range(args.rounds + 1):
