@@ -142,7 +142,8 @@ typedef struct { /* error_type, OpenCL/device/ldpc_erasure_decoder_top.cl:46-49 
     int num_RS_errors;
 } ldpc_amd_error_type;
 /* data_in(global symbol_type*, ushort nldpc, int seed, int PER_numerator_div_64, int code_ind, long numFrames)
- * (ldpc_erasure_decoder_top.cl:58-65): draws numFrames*n erasure flags with probability PER_numerator/64,
+ * (ldpc_erasure_decoder_top.cl:58-65): draws numFrames*n erasure flags with the kernel's own generator
+ * (threefry4x32-20, key {1, seed}, counter incremented per symbol, erased iff (rv & 0x3F) < PER_numerator, :74-110),
  * payload all-zero (the all-zero codeword, :77-82). data_in may be NULL (the FPGA kernel never reads it). */
 int ldpc_amd_data_in(ldpc_amd_ctx *ctx, const ldpc_amd_symbol_type *data_in, unsigned short nldpc, int seed,
                      int PER_numerator_div_64, int code_ind, long numFrames);

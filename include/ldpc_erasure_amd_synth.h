@@ -86,4 +86,50 @@ LDPC_SYNTH_FN int ldpc_synth_bernoulli(uint64_t seed, uint32_t stream, uint64_t 
     return (uint64_t)ldpc_synth_u32(seed, stream, idx) < thresh;
 }
 
+/* ------------------------------------------------------------------------------------------------------
+ * Threefry4x32-20 (Salmon, Moraes, Dror, Shaw: "Parallel Random Numbers: As Easy as 1, 2, 3", SC'11), written
+ * from the published algorithm: 20 rounds of add / rotate / xor on four 32-bit words, the rotation schedule
+ * repeating every 8 rounds, a key injection (plus round counter) every 4 rounds, key-schedule parity word
+ * 0x1BD11BDA.  The FPGA source kernel draws its erasures from it (OpenCL/device/ldpc_erasure_decoder_top.cl:74-105,
+ * vendored Random123 header OpenCL/device/threefry.h): key = {1, seed, 0, 0}, counter word 0 incremented BEFORE
+ * every draw (so symbol g of the run uses counter g + 1), and a symbol is erased iff (out[0] & 0x3F) < PER_numerator.
+ * ldpc_fpga_erased() is that rule, so ldpc_amd_data_in produces the FPGA's own erasure stream for a given seed. */
+LDPC_SYNTH_FN uint32_t ldpc_rotl32(uint32_t x, unsigned r) { return (x << r) | (x >> (32u - r)); }
+
+LDPC_SYNTH_FN void ldpc_threefry4x32_20(const uint32_t ctr[4], const uint32_t key[4], uint32_t out[4])
+{
+    const unsigned R0[8] = {10, 11, 13, 23, 6, 17, 25, 18};
+    const unsigned R1[8] = {26, 21, 27, 5, 20, 11, 10, 20};
+    uint32_t ks[5];
+    uint32_t x0, x1, x2, x3;
+    ks[4] = 0x1BD11BDAu;
+    for (int i = 0; i < 4; i++) { ks[i] = key[i]; ks[4] ^= key[i]; }
+    x0 = ctr[0] + ks[0]; x1 = ctr[1] + ks[1]; x2 = ctr[2] + ks[2]; x3 = ctr[3] + ks[3];
+    for (unsigned r = 0; r < 20; r++) {
+        if ((r & 1u) == 0) {
+            x0 += x1; x1 = ldpc_rotl32(x1, R0[r & 7]); x1 ^= x0;
+            x2 += x3; x3 = ldpc_rotl32(x3, R1[r & 7]); x3 ^= x2;
+        } else {
+            x0 += x3; x3 = ldpc_rotl32(x3, R0[r & 7]); x3 ^= x0;
+            x2 += x1; x1 = ldpc_rotl32(x1, R1[r & 7]); x1 ^= x2;
+        }
+        if ((r & 3u) == 3u) {
+            const unsigned s = (r >> 2) + 1;
+            x0 += ks[s % 5]; x1 += ks[(s + 1) % 5]; x2 += ks[(s + 2) % 5]; x3 += ks[(s + 3) % 5];
+            x3 += s;
+        }
+    }
+    out[0] = x0; out[1] = x1; out[2] = x2; out[3] = x3;
+}
+
+/* erasure flag of the g-th symbol (0-based, frames concatenated) of an FPGA data_in run */
+LDPC_SYNTH_FN int ldpc_fpga_erased(uint32_t seed, uint64_t g, int per_numerator_div_64)
+{
+    const uint32_t ctr[4] = {(uint32_t)(g + 1u), 0u, 0u, 0u};
+    const uint32_t key[4] = {1u, seed, 0u, 0u};
+    uint32_t o[4];
+    ldpc_threefry4x32_20(ctr, key, o);
+    return (int)(o[0] & 0x3Fu) < per_numerator_div_64;
+}
+
 #endif /* LDPC_ERASURE_AMD_SYNTH_H */

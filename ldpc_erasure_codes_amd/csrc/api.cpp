@@ -647,10 +647,9 @@ int ldpc_amd_data_in(ldpc_amd_ctx *ctx, const ldpc_amd_symbol_type *data_in, uns
     int rc;
     if ((rc = scratch_reserve(ctx, ctx->fpga_erased, (size_t)std::max<long>(numFrames, 1) * b->n))) return rc;
     ctx->fpga_frames = numFrames; ctx->fpga_code_ind = code_ind; ctx->fpga_per64 = PER_numerator_div_64;
-    // erased iff (rv & 0x3F) < PER_numerator_div_64 (:105): probability p/64, drawn here from the synth stream
-    const double per = PER_numerator_div_64 <= 0 ? 0.0 : (PER_numerator_div_64 >= 64 ? 1.0 : PER_numerator_div_64 / 64.0);
-    return launch_synth_erasures(ctx, (uint64_t)(uint32_t)seed, LDPC_SYNTH_STREAM_ERASE, 0, (int64_t)numFrames * b->n,
-                                 ldpc_synth_threshold(per), (uint8_t *)ctx->fpga_erased.p);
+    // erased iff (rv & 0x3F) < PER_numerator_div_64 (:105), rv from threefry4x32 with key {1, seed} and the running
+    // symbol counter (:74-75,96-98): the FPGA's own erasure stream for this seed
+    return launch_synth_fpga(ctx, (uint32_t)seed, (int64_t)numFrames * b->n, PER_numerator_div_64, (uint8_t *)ctx->fpga_erased.p);
 }
 
 int ldpc_amd_ldpc_erasure_decoder(ldpc_amd_ctx *ctx, short num_iter, int code_ind)

@@ -1014,6 +1014,14 @@ __global__ void synth_bernoulli_kernel(uint64_t seed, uint32_t stream, uint64_t 
         dst[i] = (uint8_t)ldpc_synth_bernoulli(seed, stream, base + i, thresh);
 }
 
+// erasure flags of the FPGA source kernel: threefry4x32-20, key {1, seed}, counter = symbol index + 1
+// (OpenCL/device/ldpc_erasure_decoder_top.cl:74-75,96-110; rule restated in include/ldpc_erasure_amd_synth.h)
+__global__ void synth_fpga_kernel(uint32_t seed, uint64_t count, int per64, uint8_t *dst)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x)
+        dst[i] = (uint8_t)ldpc_fpga_erased(seed, i, per64);
+}
+
 // =================================================================================================
 // Self-test of the packed multiply against the log/antilog tables
 // =================================================================================================
@@ -1457,6 +1465,15 @@ int launch_synth_source(ldpc_amd_ctx *ctx, uint64_t seed, int64_t frame0, int64_
     const uint64_t words = (count + 3) / 4;
     const int grid = (int)std::min<uint64_t>((words + 255) / 256, 16384);
     hipLaunchKernelGGL(synth_bytes_kernel, dim3(grid), dim3(256), 0, ctx->stream, seed, (uint32_t)LDPC_SYNTH_STREAM_SOURCE, base, count, d);
+    LDPC_HIP_TRY(ctx, hipGetLastError());
+    return LDPC_AMD_OK;
+}
+
+int launch_synth_fpga(ldpc_amd_ctx *ctx, uint32_t seed, int64_t count, int per64, uint8_t *d)
+{
+    if (count <= 0) return LDPC_AMD_OK;
+    const int grid = (int)std::min<int64_t>((count + 255) / 256, 16384);
+    hipLaunchKernelGGL(synth_fpga_kernel, dim3(grid), dim3(256), 0, ctx->stream, seed, (uint64_t)count, per64, d);
     LDPC_HIP_TRY(ctx, hipGetLastError());
     return LDPC_AMD_OK;
 }

@@ -95,3 +95,40 @@ def erasures_bursty(seed, frame0, nframes, n, alpha, beta, good_transition_bias,
     state[:] = st
     era = np.where(state == 0, r1 < ta, r1 < tb).astype(np.uint8)
     return era[frame0 * n:].reshape(nframes, n)
+
+
+def threefry4x32_20(ctr, key):
+    """Vectorised Threefry4x32-20 (include/ldpc_erasure_amd_synth.h): ctr [N,4] uint32, key [4] -> [N,4] uint32."""
+    R0 = (10, 11, 13, 23, 6, 17, 25, 18)
+    R1 = (26, 21, 27, 5, 20, 11, 10, 20)
+    ctr = np.asarray(ctr, dtype=np.uint32).reshape(-1, 4)
+    ks = [np.uint32(k) for k in key]
+    ks.append(np.uint32(0x1BD11BDA) ^ ks[0] ^ ks[1] ^ ks[2] ^ ks[3])
+
+    def rotl(x, r):
+        return (x << np.uint32(r)) | (x >> np.uint32(32 - r))
+
+    with np.errstate(over="ignore"):
+        x = [ctr[:, i] + ks[i] for i in range(4)]
+        for r in range(20):
+            if r % 2 == 0:
+                x[0] = x[0] + x[1]; x[1] = rotl(x[1], R0[r % 8]) ^ x[0]
+                x[2] = x[2] + x[3]; x[3] = rotl(x[3], R1[r % 8]) ^ x[2]
+            else:
+                x[0] = x[0] + x[3]; x[3] = rotl(x[3], R0[r % 8]) ^ x[0]
+                x[2] = x[2] + x[1]; x[1] = rotl(x[1], R1[r % 8]) ^ x[2]
+            if r % 4 == 3:
+                s_ = r // 4 + 1
+                for i in range(4):
+                    x[i] = x[i] + ks[(s_ + i) % 5]
+                x[3] = x[3] + np.uint32(s_)
+    return np.stack(x, axis=1)
+
+
+def fpga_erasures(seed, per64, nframes, n):
+    """Erasure flags of the FPGA data_in kernel (OpenCL/device/ldpc_erasure_decoder_top.cl:74-110)."""
+    g = np.arange(nframes * n, dtype=np.uint64)
+    ctr = np.zeros((g.size, 4), dtype=np.uint32)
+    ctr[:, 0] = ((g + np.uint64(1)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    out = threefry4x32_20(ctr, (1, np.uint32(seed & 0xFFFFFFFF), 0, 0))
+    return ((out[:, 0] & np.uint32(0x3F)) < np.uint32(max(per64, 0))).astype(np.uint8).reshape(nframes, n)

@@ -686,3 +686,23 @@ void oracle_synth_erasures_bursty(uint64_t seed, int64_t frame0, int nframes, in
         if (i >= first) erased[i - first] = (uint8_t)e;
     }
 }
+
+/* ============================ FPGA source kernel ================================================== */
+/* OpenCL/device/ldpc_erasure_decoder_top.cl:57-120 (data_in), erasure flags only */
+void oracle_threefry4x32_20(const uint32_t ctr[4], const uint32_t key[4], uint32_t out[4])
+{
+    ldpc_threefry4x32_20(ctr, key, out);
+}
+
+void oracle_fpga_data_in_erasures(int seed, int per_numerator_div_64, int64_t count, uint8_t *erased)
+{
+    const uint32_t key[4] = {1u /* tid, :69 */, (uint32_t)seed /* useed, :68 */, 0u, 0u}; /* :74 */
+    uint32_t c[4] = {0u, 0u, 0u, 0u};                                                    /* :75 */
+    for (int64_t i = 0; i < count; i++) { /* :84,89 itr over frames, k over symbols */
+        uint32_t u[4];
+        c[0]++;                           /* :96 */
+        ldpc_threefry4x32_20(c, key, u);  /* :97 */
+        long rv = (long)(int32_t)u[0];    /* :98 long rv = u.i.x */
+        erased[i] = (rv & 0x3F) < per_numerator_div_64 ? 1 : 0; /* :105-110 */
+    }
+}

@@ -115,6 +115,12 @@ void oracle_synth_erasures_uniform(uint64_t seed, int64_t frame0, int nframes, i
 void oracle_synth_erasures_bursty(uint64_t seed, int64_t frame0, int nframes, int n, double alpha,
                                   double beta, double good_transition_bias, uint8_t *erased);
 
+/* Erasure flags of the FPGA source kernel data_in (OpenCL/device/ldpc_erasure_decoder_top.cl:57-120): threefry4x32
+ * with key {1, seed} and a counter incremented before every symbol (:74-75,96-97), erased iff (rv & 0x3F) <
+ * PER_numerator_div_64 (:105).  count = numFrames * n symbols, frames concatenated. */
+void oracle_fpga_data_in_erasures(int seed, int per_numerator_div_64, int64_t count, uint8_t *erased);
+void oracle_threefry4x32_20(const uint32_t ctr[4], const uint32_t key[4], uint32_t out[4]);
+
 /* ---- batch helpers for bench.py's cpu_baseline leg (single thread each; callers may fork) ------- */
 /* Decodes nframes S=1 frames laid out like the GPU ABI (sym[nframes*n], erased[nframes*n]). */
 int oracle_ldpc_decode_batch_s1(const oracle_code *c, int nframes, const uint8_t *sym,

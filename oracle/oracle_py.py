@@ -60,6 +60,8 @@ def lib():
     L.oracle_synth_erasures_uniform.argtypes = [C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_double, u8p]
     L.oracle_synth_erasures_bursty.argtypes = [C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double,
                                                C.c_double, u8p]
+    L.oracle_fpga_data_in_erasures.argtypes = [C.c_int, C.c_int, C.c_int64, u8p]
+    L.oracle_threefry4x32_20.argtypes = [u32p, u32p, u32p]
     L.oracle_ldpc_decode_batch_s1.argtypes = [C.c_void_p, C.c_int, u8p, u8p, C.c_int, C.c_int, u8p, i32p, i32p, i32p]
     _LIB = L
     return L
@@ -202,4 +204,16 @@ def synth_erasures_uniform(seed, frame0, nframes, n, per):
 def synth_erasures_bursty(seed, frame0, nframes, n, alpha, beta, bias):
     out = np.zeros((nframes, n), dtype=np.uint8)
     lib().oracle_synth_erasures_bursty(seed, frame0, nframes, n, alpha, beta, bias, out)
+    return out
+
+
+def fpga_data_in_erasures(seed, per64, nframes, n):
+    out = np.zeros((nframes, n), dtype=np.uint8)
+    lib().oracle_fpga_data_in_erasures(seed, per64, nframes * n, out)
+    return out
+
+
+def threefry4x32_20(ctr, key):
+    out = np.zeros(4, dtype=np.uint32)
+    lib().oracle_threefry4x32_20(np.ascontiguousarray(ctr, dtype=np.uint32), np.ascontiguousarray(key, dtype=np.uint32), out)
     return out

@@ -327,7 +327,8 @@ def test_fpga_harness_statistics(ctx, oracle, code_ind, per64):
     ctx.data_in(n, seed, per64, code_ind, nframes)
     ctx.ldpc_erasure_decoder(num_iter, code_ind)
     ldpc_err, rs_err = ctx.data_out(code_ind, nframes)
-    erased = synth.erasures_uniform(seed, 0, nframes, n, per64 / 64.0)
+    erased = oracle.fpga_data_in_erasures(seed, per64, nframes, n)  # threefry stream of the FPGA kernel
+    assert np.array_equal(erased, synth.fpga_erasures(seed, per64, nframes, n))
     oc = oracle.OracleCode(code)
     want_ldpc = 0
     for f in range(nframes):

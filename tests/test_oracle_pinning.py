@@ -320,3 +320,21 @@ def test_synthesised_code_c_structure(oracle):
     era = synth.erasures_uniform(4, 0, 2, c.n, 0.12)
     out, sw, res, st = oc.decode_batch_s1(cw, era)
     assert np.array_equal(out, cw) and (st == 0).all()
+
+
+# ---------------------------------------------------------------- threefry (FPGA source kernel's generator)
+def test_threefry4x32_20_known_answers(oracle):
+    """Random123 known-answer vectors for threefry4x32, 20 rounds (the generator of
+    OpenCL/device/ldpc_erasure_decoder_top.cl:74-97).  Own implementation, include/ldpc_erasure_amd_synth.h."""
+    z = [0, 0, 0, 0]
+    f = [0xFFFFFFFF] * 4
+    assert [int(x) for x in oracle.threefry4x32_20(z, z)] == [0x9C6CA96A, 0xE17EAE66, 0xFC10ECD4, 0x5256A7D8]
+    assert [int(x) for x in oracle.threefry4x32_20(f, f)] == [0x2A881696, 0x57012287, 0xF6C7446E, 0xA16A6732]
+    ctr = np.array([z, f, [1, 2, 3, 4]], dtype=np.uint32)
+    for key in (z, f, [1, 4242, 0, 0]):
+        got = synth.threefry4x32_20(ctr, key)
+        for i in range(3):
+            assert np.array_equal(got[i], oracle.threefry4x32_20(ctr[i], key))
+    era = oracle.fpga_data_in_erasures(4242, 9, 50, 2040)
+    assert np.array_equal(era, synth.fpga_erasures(4242, 9, 50, 2040))
+    assert abs(era.mean() - 9 / 64) < 0.01
