@@ -37,7 +37,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 SEED_SRC, SEED_ERA = 20261004, 20261005
 
 
-SCATTER_KERNEL = "ldpc_scatter_kernel<16, 4, true, 8>"
+SCATTER_KERNEL = "ldpc_scatter_kernel<16, 2, true, 8>"  # LPR=16 (256-byte row pieces), 2 pieces in flight, nt, 8 waves/SIMD
 PEEL_S1_KERNEL = "ldpc_peel_kernel<16, true>"
 
 
@@ -50,8 +50,9 @@ def pmc_traffic(kernel, frames, S):
     if frames != 4096 or S not in (1, 1024) or not os.path.exists(path):
         return None
     try:
-        k = json.load(open(path))["kernels"][kernel]
-    except (KeyError, ValueError):
+        ks = json.load(open(path))["kernels"]
+        k = ks.get(kernel) or next(v for name, v in ks.items() if name.startswith(kernel.split("<")[0] + "<") and (S == 1) == ("true>" in name and "peel" in name))
+    except (KeyError, ValueError, StopIteration):
         return None
     if S == 1:  # the S = 1 launches are the large ones of that kernel in the profiled run
         return 2.0 * k["FETCH_SIZE_KB_max"] * 1024.0 + k["WRITE_SIZE_KB_max"] * 1024.0

@@ -788,206 +788,7 @@ __global__ __launch_bounds__(1024) void ldpc_scatter_big_kernel(ScatterArgs a)
     }
 }
 
-// =================================================================================================
-// Kernel C: ML stage (a2-a4) for the residual frames.  One workgroup per frame (grid-stride over the
-// compacted list).  Working set: the augmented matrix [ H(:,erased) | rhs ] , m rows of W bytes, in a
-// per-workgroup global scratch (L2 resident); pivot row and pivot column staged in LDS.
-//
-// Exactness: the reference picks as pivot the FIRST row >= col with a non-zero in column col (:86), swaps
-// it to row col (:92-97), scales it by the inverse of its leading entry (:99-105), eliminates only the rows
-// BELOW (:107-114), and on an empty column stops (:87-90) but still writes rhs(1:E) back (:127).  The same
-// sequence is executed here, so rank-deficient frames produce the reference's bytes too.
-// =================================================================================================
-struct MlArgs {
-    DevCode code;
-    int S;
-    int W;      // row stride in bytes = Wa + Spad
-    int Wa;     // bytes reserved for the matrix part (round16(m))
-    const int32_t *ml_list;
-    const uint8_t *ml_state;
-    uint8_t *out;           // [nframes][n][S]
-    uint8_t *ws;            // [gridDim.x][m][W]
-    int32_t *status;
-    // LDS offsets
-    int lds_colmap, lds_elist, lds_colv, lds_prow, lds_arow, lds_misc;
-};
-
-__global__ __launch_bounds__(256) void ldpc_ml_kernel(MlArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const DevCode &cd = a.code;
-    const int n = cd.n, m = cd.m, S = a.S, W = a.W, Wa = a.Wa;
-    const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
-    const int lane = lane_id(), wave = wave_id(), nw = nthr >> 6;
-    const int Spad = W - Wa;
-
-    uint16_t *colmap = reinterpret_cast<uint16_t *>(smem + a.lds_colmap);  // [n]
-    uint16_t *elist = reinterpret_cast<uint16_t *>(smem + a.lds_elist);    // [m]
-    uint8_t *colv = smem + a.lds_colv;                                       // [mpad]
-    U4 *prow = reinterpret_cast<U4 *>(smem + a.lds_prow);                   // [W/16]
-    uint8_t *arow = smem + a.lds_arow;                                       // [nw][Wa]
-    int *misc = reinterpret_cast<int *>(smem + a.lds_misc);                 // [0] pivot, [1] E
-
-    uint8_t *ws = a.ws + (size_t)blockIdx.x * m * W;
-    const int count = a.ml_list[0];
-
-    for (int slot = (int)blockIdx.x; slot < count; slot += (int)gridDim.x) {
-        const int64_t f = a.ml_list[1 + slot];
-        const uint8_t *state = a.ml_state + (int64_t)slot * n;
-        uint8_t *fout = a.out + f * (int64_t)n * S;
-        __syncthreads();
-
-        // ---- erasure_ind = find(y_current == -1), ascending (:63)
-        if (wave == 0) {
-            int E = 0;
-            for (int j0 = 0; j0 < n; j0 += kWave) {
-                const int j = j0 + lane;
-                const bool e = (j < n) && state[j];
-                const uint64_t mask = __ballot(e);
-                const int pos = E + __popcll(mask & ((1ull << lane) - 1ull));
-                if (j < n) colmap[j] = e ? (uint16_t)pos : (uint16_t)0xFFFFu;
-                if (e) elist[pos] = (uint16_t)j;
-                E += __popcll(mask);
-            }
-            if (lane == 0) misc[1] = E;
-        }
-        __syncthreads();
-        const int E = misc[1];
-        const int Ea = (E + 15) & ~15;
-        const int ach = Ea >> 4;          // chunks of the matrix part actually in use
-        const int rch0 = Wa >> 4;         // first rhs chunk
-        const int rch = Spad >> 4;        // rhs chunks
-
-        // ---- find_inv = H(:, erasure_ind) (:65) and rhs(kk) = sum over known neighbours (:74-82)
-        for (int r = wave; r < m; r += nw) {
-            uint8_t *ar = arow + (size_t)wave * Wa;
-            for (int i = lane; i < ach; i += kWave) reinterpret_cast<U4 *>(ar)[i] = U4{0, 0, 0, 0};
-            wave_sync();
-            const uint32_t e0 = cd.row_ptr[r], e1 = cd.row_ptr[r + 1];
-            uint8_t *wrow = ws + (size_t)r * W;
-            if (S == 1) {
-                uint32_t prod = 0;
-                if (e0 + lane < e1) {
-                    const uint32_t ed = cd.edges[e0 + lane];
-                    const uint32_t col = ed & 0xFFFFu, c = (ed >> 16) & 0xFFu;
-                    const uint32_t cm = colmap[col];
-                    if (cm != 0xFFFFu) ar[cm] = (uint8_t)c;
-                    else prod = gfmul_log(c_log, c_exp, c, fout[col]);
-                }
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) prod ^= __shfl_xor(prod, d);
-                if (lane == 0) *reinterpret_cast<U4 *>(wrow + Wa) = U4{prod, 0, 0, 0};
-            } else {
-                for (uint32_t e = e0 + lane; e < e1; e += kWave) {
-                    const uint32_t ed = cd.edges[e];
-                    const uint32_t cm = colmap[ed & 0xFFFFu];
-                    if (cm != 0xFFFFu) ar[cm] = (uint8_t)((ed >> 16) & 0xFFu);
-                }
-                for (int i = lane; i < rch; i += kWave) {
-                    U4 acc = {0, 0, 0, 0};
-                    for (uint32_t e = e0; e < e1; e++) {
-                        const uint32_t ed = cd.edges[e];
-                        const uint32_t col = ed & 0xFFFFu, c = (ed >> 16) & 0xFFu;
-                        if (colmap[col] != 0xFFFFu) continue;
-                        const U4 v = *reinterpret_cast<const U4 *>(fout + (int64_t)col * S + i * 16);
-                        gfmac16(acc, load_multab(c), v);
-                    }
-                    *reinterpret_cast<U4 *>(wrow + Wa + i * 16) = acc;
-                }
-            }
-            wave_sync();
-            for (int i = lane; i < ach; i += kWave)
-                reinterpret_cast<U4 *>(wrow)[i] = reinterpret_cast<const U4 *>(ar)[i];
-            wave_sync();
-        }
-        if (tid == 0) misc[0] = 0x7FFFFFFF;
-        __syncthreads();
-
-        // ---- forward elimination (:85-115)
-        int dont_do_jordan = 0;
-        for (int col = 0; col < E; col++) {
-            for (int r = col + tid; r < m; r += nthr) {   // :86 non_zero_ind = find(find_inv(col:end, col))
-                const uint8_t v = ws[(size_t)r * W + col];
-                colv[r] = v;
-                if (v) atomicMin(&misc[0], r);
-            }
-            __syncthreads();
-            const int p = misc[0];
-            if (p == 0x7FFFFFFF) { dont_do_jordan = 1; break; }   // :87-90
-            // swap rows col <-> p (:92-97), scale the pivot row by the inverse of its leading entry (:99-105)
-            {
-                const uint32_t pinv = c_inv[colv[p]];
-                const MulTab t = load_multab(pinv);
-                const int c0 = col >> 4;
-                uint8_t *rp = ws + (size_t)p * W, *rc = ws + (size_t)col * W;
-                for (int i = tid; i < (ach - c0) + rch; i += nthr) {
-                    const int ci = (i < ach - c0) ? (c0 + i) : (rch0 + (i - (ach - c0)));
-                    const U4 vp = *reinterpret_cast<const U4 *>(rp + ci * 16);
-                    const U4 sc = gfmul16(t, vp);
-                    if (p != col) {
-                        const U4 vc = *reinterpret_cast<const U4 *>(rc + ci * 16);
-                        *reinterpret_cast<U4 *>(rp + ci * 16) = vc;
-                    }
-                    *reinterpret_cast<U4 *>(rc + ci * 16) = sc;
-                    prow[ci] = sc;
-                }
-            }
-            __syncthreads();
-            // zero out the other non-zero rows below (:107-114); rows in (col, p] are zero in this column
-            for (int r = p + 1 + wave; r < m; r += nw) {
-                const uint32_t fct = colv[r];
-                if (fct == 0) continue;
-                const MulTab t = load_multab(uniform(fct));
-                const int c0 = col >> 4;
-                uint8_t *rr = ws + (size_t)r * W;
-                for (int i = lane; i < (ach - c0) + rch; i += kWave) {
-                    const int ci = (i < ach - c0) ? (c0 + i) : (rch0 + (i - (ach - c0)));
-                    U4 v = *reinterpret_cast<const U4 *>(rr + ci * 16);
-                    gfmac16(v, t, prow[ci]);
-                    *reinterpret_cast<U4 *>(rr + ci * 16) = v;
-                }
-            }
-            if (tid == 0) misc[0] = 0x7FFFFFFF;
-            __syncthreads();
-        }
-
-        // ---- Jordan elimination on the upper triangle, rhs only (:117-126)
-        if (!dont_do_jordan) {
-            for (int col = E - 1; col >= 1; col--) {
-                for (int r = tid; r < col; r += nthr) colv[r] = ws[(size_t)r * W + col];
-                for (int i = tid; i < rch; i += nthr)
-                    prow[rch0 + i] = *reinterpret_cast<const U4 *>(ws + (size_t)col * W + Wa + i * 16);
-                __syncthreads();
-                for (int r = wave; r < col; r += nw) {
-                    const uint32_t fct = colv[r];
-                    if (fct == 0) continue;
-                    const MulTab t = load_multab(uniform(fct));
-                    uint8_t *rr = ws + (size_t)r * W + Wa;
-                    for (int i = lane; i < rch; i += kWave) {
-                        U4 v = *reinterpret_cast<const U4 *>(rr + i * 16);
-                        gfmac16(v, t, prow[rch0 + i]);
-                        *reinterpret_cast<U4 *>(rr + i * 16) = v;
-                    }
-                }
-                __syncthreads();
-            }
-        }
-
-        // ---- y_current(erasure_ind) = rhs(1:num_erasures) -- unconditional (:127)
-        if (S == 1) {
-            for (int t = tid; t < E; t += nthr) fout[elist[t]] = ws[(size_t)t * W + Wa];
-        } else {
-            for (int t = wave; t < E; t += nw) {
-                const uint8_t *src = ws + (size_t)t * W + Wa;
-                uint8_t *dst = fout + (int64_t)elist[t] * S;
-                for (int i = lane; i < rch; i += kWave)
-                    *reinterpret_cast<U4 *>(dst + i * 16) = *reinterpret_cast<const U4 *>(src + i * 16);
-            }
-        }
-        if (tid == 0 && a.status) a.status[f] = dont_do_jordan ? LDPC_AMD_ST_ML_RANKDEF : LDPC_AMD_ST_ML_SOLVED;
-        if (tid == 0) misc[0] = 0x7FFFFFFF;
-    }
-}
+#include "ml_kernel.inc"
 
 // =================================================================================================
 // Synthetic inputs (role of the FPGA data_in kernel, OpenCL/device/ldpc_erasure_decoder_top.cl:57-120)
@@ -1328,29 +1129,31 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     if (d.do_ml) {
         MlArgs ma{};
         ma.code = cd; ma.S = d.S;
-        ma.Wa = align_up(cd.m, 16);
-        const int Spad = fused ? 16 : d.S;
-        ma.W = ma.Wa + Spad;
+        ma.Spad = fused ? 16 : d.S;
         ma.ml_list = (const int32_t *)ctx->mllist.p; ma.ml_state = (const uint8_t *)ctx->mlstate.p;
         ma.out = d.out; ma.status = d.status;
-        const int nwv = 4;
+        const int maxrow = align_up(cd.m, 16) + 16;
         int off = 0;
         ma.lds_colmap = off; off += align_up(2 * cd.n, 16);
         ma.lds_elist = off; off += align_up(2 * cd.m, 16);
         ma.lds_colv = off; off += align_up(cd.mpad, 16);
-        ma.lds_prow = off; off += ma.W;
-        ma.lds_arow = off; off += nwv * ma.Wa;
-        ma.lds_misc = off; off += 16;
+        ma.lds_rlist = off; off += align_up(2 * cd.m, 16);
+        ma.lds_prow = off; off += maxrow + (fused ? 0 : d.S);
+        ma.lds_mt = off; off += 8192;
+        ma.lds_misc = off; off += 64;
+        ma.lds_A = off;
         if (off > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "ML stage: LDS need %d bytes", off);
-        int grid = (int)std::min<int64_t>(nf, 2 * (int64_t)ctx->sm_count);
-        const size_t per = (size_t)cd.m * ma.W;
-        while (grid > 1 && per * grid > ((size_t)8 << 30)) grid >>= 1;
-        if ((rc = scratch_reserve(ctx, ctx->mlws, per * grid))) return rc;
-        ma.ws = (uint8_t *)ctx->mlws.p;
+        ma.capA = (kLdsMax - off) & ~15;
+        const int total = kLdsMax;
+        int grid = (int)std::min<int64_t>(nf, (int64_t)ctx->sm_count);
+        const size_t perA = (size_t)cd.m * maxrow, perR = fused ? 0 : (size_t)cd.m * d.S;
+        if ((rc = scratch_reserve(ctx, ctx->mlws, (perA + perR) * grid))) return rc;
+        ma.wsA = (uint8_t *)ctx->mlws.p;
+        ma.wsR = ma.wsA + perA * grid;
         auto kfn = ldpc_ml_kernel;
-        LDPC_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, off));
+        LDPC_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, total));
         hipEvent_t ev = prof_begin(ctx);
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(nwv * 64), (size_t)off, ctx->stream, ma);
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(1024), (size_t)total, ctx->stream, ma);
         LDPC_HIP_TRY(ctx, hipGetLastError());
         prof_end(ctx, LDPC_AMD_PROF_ML, ev);
     }
