@@ -1,0 +1,108 @@
+"""GPU tests of the boundary itself: error behaviour (int codes + last_error, no exceptions across the ABI), empty and
+ragged batches, properties the domain offers at sizes the oracle would not finish (linearity, idempotence), and the
+C++ host harness that mirrors OpenCL/host/src/main.cpp."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from ldpc_erasure_codes_amd import api, codes, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def test_error_codes_and_messages(ctx, code_a):
+    h = ctx.load_builtin_code(1, 2040)
+    L = api.load_library()
+    sym = np.zeros((1, code_a.n, 24), dtype=np.uint8)  # S = 24 is neither 1 nor a multiple of 16
+    era = np.zeros((1, code_a.n), dtype=np.uint8)
+    out = np.zeros_like(sym)
+    rc = L.ldpc_amd_decode_batch(ctx._h, h, 24, 1, sym.ctypes.data, era.ctypes.data, 10, 1, out.ctypes.data, None, None, None, 0)
+    assert rc == -5 and b"multiple of 16" in L.ldpc_amd_last_error(ctx._h)
+    rc = L.ldpc_amd_decode_batch(ctx._h, 999, 1, 1, sym.ctypes.data, era.ctypes.data, 10, 1, out.ctypes.data, None, None, None, 0)
+    assert rc == -4
+    rc = L.ldpc_amd_decode_batch(ctx._h, h, 1, 1, None, era.ctypes.data, 10, 1, out.ctypes.data, None, None, None, 0)
+    assert rc == -1
+    rc = L.ldpc_amd_decode_batch(ctx._h, h, 1, 1, sym.ctypes.data, era.ctypes.data, 0, 1, out.ctypes.data, None, None, None, 0)
+    assert rc == -1 and b"max_sweeps" in L.ldpc_amd_last_error(ctx._h)
+    # nframes = 0 is a no-op, not an error
+    assert L.ldpc_amd_decode_batch(ctx._h, h, 1, 0, None, None, 10, 1, None, None, None, None, 0) == 0
+    with pytest.raises(api.LdpcAmdError):
+        ctx.load_builtin_code(17, 1)
+    with pytest.raises(api.LdpcAmdError):
+        ctx.rs_create(300, 10)
+    # malformed custom codes are rejected with a message
+    bad = codes.from_dense(np.array([[1, 1, 0], [0, 1, 1]], dtype=np.uint8), 1)
+    bad.cols = bad.cols[::-1].copy()
+    with pytest.raises(api.LdpcAmdError):
+        ctx.register_code(bad)
+
+
+def test_status_pointers_are_optional_and_batches_can_be_ragged(ctx, oracle, code_a):
+    h = ctx.load_builtin_code(1, codes.DEFAULT_COEF_SEED[1])
+    oc = oracle.OracleCode(code_a)
+    L = api.load_library()
+    for nframes in (1, 3, 5, 67):  # not multiples of the frames-per-workgroup
+        src = synth.source(70, 0, nframes, code_a.k, 1)[:, :, 0]
+        cw = ctx.encode(h, src)
+        era = synth.erasures_uniform(71, 0, nframes, code_a.n, 0.15)
+        sym = cw.copy()
+        sym[era.astype(bool)] = 1
+        out = np.zeros_like(sym)
+        rc = L.ldpc_amd_decode_batch(ctx._h, h, 1, nframes, sym.ctypes.data, era.ctypes.data, 10, 1, out.ctypes.data, None, None, None, 0)
+        assert rc == 0 and np.array_equal(out, cw)
+    assert np.array_equal(cw[0], oc.encode(src[0]))
+
+
+def test_linearity_and_idempotence_at_full_batch_size(code_a):
+    """Decoding is GF(256)-linear in the received values for a fixed erasure pattern, and decoding a decoded word
+    again (nothing erased) returns it unchanged -- checked on 4096 frames of 64-byte packets."""
+    torch = pytest.importorskip("torch")
+    ctx = api.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    h = ctx.load_builtin_code(1, codes.DEFAULT_COEF_SEED[1])
+    F, S, n, k = 4096, 64, code_a.n, code_a.k
+    dev = torch.device("cuda", 0)
+    a = torch.empty((F, k, S), dtype=torch.uint8, device=dev)
+    b = torch.empty((F, k, S), dtype=torch.uint8, device=dev)
+    ctx.synth_source(81, 0, F, k, S, a)
+    ctx.synth_source(82, 0, F, k, S, b)
+    ca, cb = ctx.encode(h, a), ctx.encode(h, b)
+    cab = ctx.encode(h, a ^ b)
+    ctx.synchronize()
+    assert torch.equal(cab, ca ^ cb)  # encoder linearity
+    era = torch.empty((F, n), dtype=torch.uint8, device=dev)
+    ctx.synth_erasures_uniform(83, 0, F, n, 0.19, era)  # MP-only and ML frames mixed
+    da, _, _, sta = ctx.decode(h, ca, era)
+    db, _, _, _ = ctx.decode(h, cb, era)
+    dab, _, _, _ = ctx.decode(h, ca ^ cb, era)
+    ctx.synchronize()
+    ok = sta <= 1
+    assert bool(ok.any()) and torch.equal(dab[ok], (da ^ db)[ok])
+    assert torch.equal(da[ok], ca[ok])
+    again, sw, res, st = ctx.decode(h, da, torch.zeros_like(era))
+    ctx.synchronize()
+    assert torch.equal(again, da) and int(sw.max()) == 1 and int(st.max()) == 0
+    ctx.close()
+
+
+def test_cpp_host_harness_passes():
+    """ldpc_erasure_codes_amd/host/main.cpp: init_opencl -> run -> verify_output -> cleanup with the reference's CLI."""
+    exe = os.path.join(ROOT, "ldpc_erasure_codes_amd", "host", "ldpc_erasure_decoder_host")
+    if not os.path.exists(exe):
+        pytest.skip("host harness not built")
+    r = subprocess.run([exe, "-h", "-c", "1", "-p", "9", "-n", "2000", "-i", "50"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "PASSED" in r.stdout and "FAILED" not in r.stdout
+    assert "frame error rate" in r.stdout and "throughput in information bits/sec" in r.stdout
+    r = subprocess.run([exe, "-e", "-c", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "PASSED" in r.stdout
