@@ -255,6 +255,20 @@ static int register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_pt
             for (uint32_t e = row_ptr[r]; e < row_ptr[r + 1]; e++)
                 cell[((size_t)cols[e] << cdw_shift) + cdeg[cols[e]]++] = (uint32_t)r | ((uint32_t)hc->coefs[e] << 16);
     }
+    // static per-symbol lists of the encoder (every check is used; slot = position in the level-sorted schedule;
+    // the check whose target is the symbol itself is left out), same layout as the decoder's per-frame lists
+    std::vector<uint32_t> enc_src((size_t)n << cdw_shift, 0xFFFFFFFFu);
+    if (enc_nlevels > 0) {
+        std::vector<uint32_t> slot_of_row(m, 0);
+        for (int s_ = 0; s_ < m; s_++) slot_of_row[enc_steps[s_] & 0xFFFFu] = (uint32_t)s_;
+        std::vector<int> fillc(n, 0);
+        for (int r = 0; r < m; r++)
+            for (uint32_t e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
+                const int j = cols[e];
+                if (j == k + r) continue;
+                enc_src[((size_t)j << cdw_shift) + fillc[j]++] = slot_of_row[r] | ((uint32_t)hc->coefs[e] << 16);
+            }
+    }
     DevCode &d = hc->dev;
     d.n = n; d.k = k; d.m = m; d.nnz = hc->nnz; d.maxdeg = maxdeg; d.degpad = degpad; d.mpad = mpad;
     d.maxcoldeg = maxcoldeg; d.cdw_shift = cdw_shift;
@@ -263,6 +277,7 @@ static int register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_pt
     if ((rc = upload(ctx, hc, hc->row_ptr, &d.row_ptr)) || (rc = upload(ctx, hc, edges, &d.edges)) ||
         (rc = upload(ctx, hc, ell_col, &d.ell_col)) || (rc = upload(ctx, hc, ell_logc, &d.ell_logc)) ||
         (rc = upload(ctx, hc, ell_coef, &d.ell_coef)) || (rc = upload(ctx, hc, cell, &d.cell)) ||
+        (rc = upload(ctx, hc, enc_src, &d.enc_src)) ||
         (rc = upload(ctx, hc, enc_steps, &d.enc_steps)) || (rc = upload(ctx, hc, enc_lvlend, &d.enc_lvlend))) {
         free_code(hc);
         return rc;

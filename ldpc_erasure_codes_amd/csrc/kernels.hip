@@ -570,6 +570,8 @@ struct ScatterArgs {
     const uint32_t *sched_steps;
     const uint16_t *sched_lvlend;
     const uint32_t *src_pad;
+    int in_rows;              // rows per input frame: n (decode) or k (encode: rows >= k are the unknowns)
+    int static_sched;         // encode: the code's static schedule / lists are used for every frame
     int tcap;                 // tier 1 handles frames with at most tcap steps (its LDS holds tcap accumulators)
     const int32_t *big_list;  // tier 2: [0] = count, [1..] ids of the frames with more steps; nullptr in tier 1
     int lds_acc, lds_tgt, lds_invc, lds_lvlend, lds_solved, lds_mt, lds_soc;
@@ -640,9 +642,10 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     uint32_t *mt = reinterpret_cast<uint32_t *>(smem + a.lds_mt);
     uint8_t *rk = smem + a.lds_soc;  // row kinds, [n]
 
-    const int nsteps = (int)a.sched_hdr[2 * f], nlev = (int)a.sched_hdr[2 * f + 1];
-    const uint32_t *gs = a.sched_steps + f * cd.m;
-    const uint16_t *gle = a.sched_lvlend + f * (cd.m + 1);
+    const int nsteps = a.static_sched ? cd.m : (int)a.sched_hdr[2 * f];
+    const int nlev = a.static_sched ? cd.enc_nlevels : (int)a.sched_hdr[2 * f + 1];
+    const uint32_t *gs = a.static_sched ? cd.enc_steps : a.sched_steps + f * cd.m;
+    const uint16_t *gle = a.static_sched ? cd.enc_lvlend : a.sched_lvlend + f * (cd.m + 1);
     for (int i = tid; i < (n + 31) / 32; i += nthr) solved[i] = 0;
     for (int i = tid; i < 2048; i += nthr) mt[i] = c_mul3[i];
     for (int i = tid; i <= nlev; i += nthr) lvlend[i] = gle[i];
@@ -662,15 +665,17 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     }
     __syncthreads();
     {   // row kinds: 1 received, 2 erased and never solved (written as 0), 0 erased and solved in phase B
-        const uint8_t *erf = a.erased + f * (int64_t)n;
-        for (int j = tid; j < n; j += nthr)
-            rk[j] = erf[j] ? (((solved[j >> 5] >> (j & 31)) & 1u) ? (uint8_t)0 : (uint8_t)2) : (uint8_t)1;
+        const uint8_t *erf = a.erased ? a.erased + f * (int64_t)n : nullptr;
+        for (int j = tid; j < n; j += nthr) {
+            const bool e = erf ? (erf[j] != 0) : (j >= a.in_rows);
+            rk[j] = e ? (((solved[j >> 5] >> (j & 31)) & 1u) ? (uint8_t)0 : (uint8_t)2) : (uint8_t)1;
+        }
     }
     __syncthreads();
 
-    const uint8_t *fin = a.sym + f * (int64_t)n * S + (int64_t)sl * B + gl * 16;
+    const uint8_t *fin = a.sym + f * (int64_t)a.in_rows * S + (int64_t)sl * B + gl * 16;
     uint8_t *fout = a.out + f * (int64_t)n * S + (int64_t)sl * B + gl * 16;
-    const uint32_t *spad = a.src_pad + ((f * (int64_t)n) << cd.cdw_shift);
+    const uint32_t *spad = a.static_sched ? cd.enc_src : a.src_pad + ((f * (int64_t)n) << cd.cdw_shift);
 
     // multiplies v into the accumulators of the steps that symbol j feeds: ew = the symbol's list, entry t held by
     // lane (t % LPR) of the group, 0xFFFFFFFF = no entry.  Every group walks the set bits of its own validity mask.
@@ -772,7 +777,7 @@ __global__ __launch_bounds__(1024, WPE) void ldpc_scatter_kernel(ScatterArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int64_t f = blockIdx.x / a.nslices;
     const int sl = (int)(blockIdx.x % a.nslices);
-    if ((int)a.sched_hdr[2 * f] > a.tcap) return;
+    if (!a.static_sched && (int)a.sched_hdr[2 * f] > a.tcap) return;
     scatter_frame<LPR, R, NT>(a, smem, f, sl);
 }
 
@@ -1109,6 +1114,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         if (use_scatter) {
             ScatterArgs sa{};
             sa.code = cd; sa.S = d.S; sa.nslices = plan.nslices; sa.nframes = nf; sa.sym = d.sym; sa.erased = d.erased; sa.out = d.out;
+            sa.in_rows = cd.n; sa.static_sched = 0;
             sa.sched_hdr = pa.sched_hdr; sa.sched_steps = pa.sched_steps; sa.sched_lvlend = pa.sched_lvlend;
             sa.src_pad = pa.src_pad;
             ev = prof_begin(ctx);
@@ -1172,6 +1178,18 @@ int launch_encode(ldpc_amd_ctx *ctx, const DevCode &cd, int S, int64_t nframes, 
         return launch_decode(ctx, d);
     }
     if (S % 16) return set_error(ctx, LDPC_AMD_EUNSUP, "S must be 1 or a multiple of 16 (got %d)", S);
+    const char *apply_env = getenv("LDPC_AMD_APPLY");
+    if (!(apply_env && strcmp(apply_env, "gather") == 0) && cd.maxcoldeg <= 16) {
+        // scatter form with the static schedule: source rows read once, all m accumulators in LDS
+        ScatterPlan plan = plan_scatter(cd, S);
+        if (plan.lpr > 0) {
+            plan.two_tier = false; plan.tcap = cd.m; plan.lds1 = plan.lds2;
+            ScatterArgs sa{};
+            sa.code = cd; sa.S = S; sa.nslices = plan.nslices; sa.nframes = nframes; sa.sym = src; sa.erased = nullptr; sa.out = cw;
+            sa.in_rows = cd.k; sa.static_sched = 1;
+            return launch_scatter(ctx, plan, sa, nullptr);
+        }
+    }
     ApplyArgs aa{};
     aa.code = cd; aa.S = S; aa.nframes = nframes; aa.sym = src; aa.erased = nullptr; aa.in_rows = cd.k; aa.out = cw;
     const size_t lds = (size_t)cd.m * 4 + (size_t)(cd.m + 2) * 2;
