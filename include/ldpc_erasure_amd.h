@@ -40,6 +40,10 @@ extern "C" {
 
 /* flags */
 #define LDPC_AMD_DEVICE_PTRS 1u /* every data pointer of the call is a device pointer; call is async */
+#define LDPC_AMD_INPLACE 2u     /* ldpc_amd_decode_batch with out == sym (device pointers, S >= 16): received symbols are
+                                   left where they are and only the erased ones are written -- about half the HBM traffic.
+                                   The reference returns a copy (Matlab value semantics, separate FPGA output buffer); this
+                                   is an extension for callers that own the frame buffer. */
 
 /* per-frame status[] values */
 #define LDPC_AMD_ST_MP_DONE 0      /* message passing recovered everything                            */

@@ -24,6 +24,7 @@ LIB_PATH = os.path.join(_HERE, "libldpc_erasure_amd.so")
 
 OK = 0
 DEVICE_PTRS = 1
+INPLACE = 2
 ST_MP_DONE, ST_ML_SOLVED, ST_ML_RANKDEF, ST_ML_SKIPPED = 0, 1, 2, 3
 
 # every symbol include/ldpc_erasure_amd.h declares (checked by tests/test_abi.py)
@@ -205,7 +206,8 @@ class Context:
         return rp, cols, coefs
 
     # -- hot path
-    def decode(self, code, sym, erased, max_sweeps=10, do_ml=1, out=None, sweeps=None, residual=None, status=None):
+    def decode(self, code, sym, erased, max_sweeps=10, do_ml=1, out=None, sweeps=None, residual=None, status=None,
+               inplace=False):
         """sym [F,n,S] (or [F,n] for S=1) uint8, erased [F,n] uint8.
         numpy in -> numpy out (synchronous).  torch CUDA tensors in -> torch out (asynchronous).
         Returns (out, sweeps, residual, status)."""
@@ -217,6 +219,8 @@ class Context:
         if dev:
             import torch
             mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=sym.device)  # noqa: E731
+            if inplace:
+                out = sym
             out = mk(tuple(sym.shape), torch.uint8) if out is None else out
             sweeps = mk((F,), torch.int32) if sweeps is None else sweeps
             residual = mk((F,), torch.int32) if residual is None else residual
@@ -230,7 +234,7 @@ class Context:
             status = np.empty(F, dtype=np.int32) if status is None else status
         self._check(self._L.ldpc_amd_decode_batch(self._h, code, S, F, _ptr(sym), _ptr(erased), max_sweeps, do_ml,
                                                   _ptr(out), _ptr(sweeps), _ptr(residual), _ptr(status),
-                                                  DEVICE_PTRS if dev else 0), "decode_batch")
+                                                  (DEVICE_PTRS if dev else 0) | (INPLACE if inplace else 0)), "decode_batch")
         return out, sweeps, residual, status
 
     def encode(self, code, source, out=None):

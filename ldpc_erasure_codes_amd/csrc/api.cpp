@@ -451,8 +451,13 @@ int ldpc_amd_decode_batch(ldpc_amd_ctx *ctx, int code, int S, int64_t nframes, c
     d.code = hc->dev; d.S = S; d.nframes = nframes; d.in_rows = hc->n; d.max_sweeps = max_sweeps; d.do_ml = do_ml ? 1 : 0;
     if (flags & LDPC_AMD_DEVICE_PTRS) {
         d.sym = sym; d.erased = erased; d.out = out; d.sweeps = sweeps; d.residual = residual; d.status = status;
+        if (flags & LDPC_AMD_INPLACE) {
+            if (out != sym || S < 16) return set_error(ctx, LDPC_AMD_EINVAL, "LDPC_AMD_INPLACE needs out == sym and S >= 16");
+            d.inplace = 1;
+        }
         return launch_decode(ctx, d);
     }
+    if (flags & LDPC_AMD_INPLACE) return set_error(ctx, LDPC_AMD_EINVAL, "LDPC_AMD_INPLACE needs LDPC_AMD_DEVICE_PTRS");
     int rc;
     if ((rc = scratch_reserve(ctx, ctx->stage_in, fbytes * nframes)) || (rc = scratch_reserve(ctx, ctx->stage_er, (size_t)hc->n * nframes)) ||
         (rc = scratch_reserve(ctx, ctx->stage_out, fbytes * nframes)) || (rc = scratch_reserve(ctx, ctx->stage_i32, 3 * sizeof(int32_t) * (size_t)nframes)))

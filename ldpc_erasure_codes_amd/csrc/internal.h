@@ -122,6 +122,7 @@ struct DecodeArgs {
     int32_t *sweeps, *residual, *status;  // may be nullptr
     int flags_only = 0;                   // peel only (no data movement): FPGA-harness statistics
     int32_t *residual_sys = nullptr;      // [nframes] unknown symbols among the first k, or nullptr
+    int inplace = 0;                      // out == sym: received rows are not rewritten
 };
 
 hipError_t upload_constants(hipStream_t s);

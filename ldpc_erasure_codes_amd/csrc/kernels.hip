@@ -572,6 +572,7 @@ struct ScatterArgs {
     const uint32_t *src_pad;
     int in_rows;              // rows per input frame: n (decode) or k (encode: rows >= k are the unknowns)
     int static_sched;         // encode: the code's static schedule / lists are used for every frame
+    int inplace;              // out == sym: received rows stay where they are, only erased rows are written
     int tcap;                 // tier 1 handles frames with at most tcap steps (its LDS holds tcap accumulators)
     const int32_t *big_list;  // tier 2: [0] = count, [1..] ids of the frames with more steps; nullptr in tier 1
     int lds_acc, lds_tgt, lds_invc, lds_lvlend, lds_solved, lds_mt, lds_soc;
@@ -735,7 +736,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const int j = j0 + r * RPW + g;
-                if (cur.kind[r]) stream_store16<NT>(fout + (int64_t)j * S, cur.v[r]);
+                if (cur.kind[r] == 2 || (cur.kind[r] == 1 && !a.inplace)) stream_store16<NT>(fout + (int64_t)j * S, cur.v[r]);
                 scatter(cur.v[r], cur.ew[r]);
             }
             cur = nxt;
@@ -1063,6 +1064,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     ScatterPlan plan{};
     if (!fused && !d.flags_only && !want_gather && cd.maxcoldeg <= 16) plan = plan_scatter(cd, d.S);
     const bool use_scatter = plan.lpr > 0;
+    if (d.inplace && !use_scatter) return set_error(ctx, LDPC_AMD_EUNSUP, "in-place decode needs the scatter kernel");
 
     // workgroup shape: as many frames per workgroup as fit comfortably in LDS
     int wpb = 4;
@@ -1114,7 +1116,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         if (use_scatter) {
             ScatterArgs sa{};
             sa.code = cd; sa.S = d.S; sa.nslices = plan.nslices; sa.nframes = nf; sa.sym = d.sym; sa.erased = d.erased; sa.out = d.out;
-            sa.in_rows = cd.n; sa.static_sched = 0;
+            sa.in_rows = cd.n; sa.static_sched = 0; sa.inplace = d.inplace;
             sa.sched_hdr = pa.sched_hdr; sa.sched_steps = pa.sched_steps; sa.sched_lvlend = pa.sched_lvlend;
             sa.src_pad = pa.src_pad;
             ev = prof_begin(ctx);

@@ -95,6 +95,35 @@ def test_linearity_and_idempotence_at_full_batch_size(code_a):
     ctx.close()
 
 
+def test_inplace_decode_extension(code_a):
+    """LDPC_AMD_INPLACE (out == sym): only erased symbols are written; result equals the out-of-place decode,
+    including frames that go through the ML stage."""
+    torch = pytest.importorskip("torch")
+    ctx = api.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    h = ctx.load_builtin_code(1, codes.DEFAULT_COEF_SEED[1])
+    F, S, n, k = 64, 1024, code_a.n, code_a.k
+    dev = torch.device("cuda", 0)
+    src = torch.empty((F, k, S), dtype=torch.uint8, device=dev)
+    ctx.synth_source(91, 0, F, k, S, src)
+    cw = ctx.encode(h, src)
+    era = torch.empty((F, n), dtype=torch.uint8, device=dev)
+    ctx.synth_erasures_uniform(92, 0, F // 2, n, 0.10, era[: F // 2])
+    ctx.synth_erasures_uniform(93, 0, F // 2, n, 0.21, era[F // 2:])
+    sym = cw.clone()
+    sym[era.bool()] = 0xC3
+    ref, sw, res, st = ctx.decode(h, sym, era)
+    buf = sym.clone()
+    out, sw2, res2, st2 = ctx.decode(h, buf, era, inplace=True)
+    ctx.synchronize()
+    assert out.data_ptr() == buf.data_ptr()
+    assert torch.equal(buf, ref) and torch.equal(sw, sw2) and torch.equal(st, st2)
+    assert int((st == 1).sum()) > 0  # the ML stage was exercised
+    with pytest.raises(api.LdpcAmdError):
+        ctx.decode(h, np.zeros((1, n, 16), np.uint8), np.zeros((1, n), np.uint8), inplace=True)  # host pointers
+    ctx.close()
+
+
 def test_cpp_host_harness_passes():
     """ldpc_erasure_codes_amd/host/main.cpp: init_opencl -> run -> verify_output -> cleanup with the reference's CLI."""
     exe = os.path.join(ROOT, "ldpc_erasure_codes_amd", "host", "ldpc_erasure_decoder_host")
