@@ -215,7 +215,7 @@ struct PeelArgs {
 };
 
 template <int MAXDEG, bool FUSED_S1>
-__global__ __launch_bounds__(256) void ldpc_peel_kernel(PeelArgs a)
+__global__ __launch_bounds__(1024) void ldpc_peel_kernel(PeelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const DevCode &cd = a.code;
@@ -250,47 +250,41 @@ __global__ __launch_bounds__(256) void ldpc_peel_kernel(PeelArgs a)
 
     unsigned char *wbase = smem + a.lds.wave0 + wave * a.lds.wave_stride;
     uint16_t *st = reinterpret_cast<uint16_t *>(wbase + a.lds.st);
-    uint8_t *y = wbase + a.lds.y;
     uint32_t *steps = reinterpret_cast<uint32_t *>(wbase + a.lds.steps);
     uint16_t *slvl = reinterpret_cast<uint16_t *>(wbase + a.lds.slvl);
     uint32_t *sorted = reinterpret_cast<uint32_t *>(wbase + a.lds.sorted);
 
-    // ---- load the frame's erasure flags (and, for S == 1, its symbols)
+    // ---- load the frame's erasure flags (the symbols of an S == 1 frame are loaded after the peel, see below)
     int remaining = 0;
+    const uint8_t *er = a.erased ? a.erased + f * n : nullptr;
+    const uint8_t *sy = FUSED_S1 ? a.sym + f * a.in_rows : nullptr;
+    const bool fast = ((n & 7) == 0) && ((a.in_rows & 7) == 0) && ((reinterpret_cast<uintptr_t>(er) & 7) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(sy) & 7) == 0);
     {
-        const uint8_t *er = a.erased ? a.erased + f * n : nullptr;
-        const uint8_t *sy = FUSED_S1 ? a.sym + f * a.in_rows : nullptr;
-        const bool fast = ((n & 7) == 0) && ((a.in_rows & 7) == 0) && ((reinterpret_cast<uintptr_t>(er) & 7) == 0) &&
-                          ((reinterpret_cast<uintptr_t>(sy) & 7) == 0);
         if (fast) {
-            // 8 flags (and 8 symbols) per 64-bit load, 4 independent loads in flight per lane
+            // 8 flags per 64-bit load, 4 independent loads in flight per lane
             constexpr int U = 4;
             const int nq = n >> 3;
             const uint64_t *er64 = reinterpret_cast<const uint64_t *>(er);
-            const uint64_t *sy64 = reinterpret_cast<const uint64_t *>(sy);
             int cnt = 0;
             for (int q0 = 0; q0 < nq; q0 += kWave * U) {
-                uint64_t ew[U], sw[U];
+                uint64_t ew[U];
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     const int q = q0 + u * kWave + lane;
                     ew[u] = (er && q < nq) ? er64[q] : 0ull;
-                    sw[u] = (FUSED_S1 && q < nq && q * 8 < a.in_rows) ? sy64[q] : 0ull;
                 }
 #pragma unroll
                 for (int u = 0; u < U; u++) {
                     const int q = q0 + u * kWave + lane;
                     if (q < nq) {
                         uint32_t s4[4] = {0, 0, 0, 0};
-                        uint64_t yv = 0;
 #pragma unroll
                         for (int b = 0; b < 8; b++) {
                             const bool e = er ? (((ew[u] >> (8 * b)) & 0xFFull) != 0) : (q * 8 + b >= a.in_rows);
                             if (e) { s4[b >> 1] |= 0xFFFFu << (16 * (b & 1)); cnt++; }
-                            else yv |= ((sw[u] >> (8 * b)) & 0xFFull) << (8 * b);
                         }
                         *reinterpret_cast<U4 *>(st + q * 8) = U4{s4[0], s4[1], s4[2], s4[3]};
-                        if (FUSED_S1) *reinterpret_cast<uint64_t *>(y + q * 8) = yv;
                     }
                 }
             }
@@ -304,7 +298,6 @@ __global__ __launch_bounds__(256) void ldpc_peel_kernel(PeelArgs a)
                 if (j < n) {
                     e = er ? (er[j] != 0) : (j >= a.in_rows);
                     st[j] = e ? (uint16_t)0xFFFFu : (uint16_t)0;
-                    if (FUSED_S1) y[j] = (e || j >= a.in_rows) ? (uint8_t)0 : sy[j];
                 }
                 remaining += __popcll(__ballot(e));
             }
@@ -405,6 +398,43 @@ __global__ __launch_bounds__(256) void ldpc_peel_kernel(PeelArgs a)
         LDPC_STAMP(5);  // per-source lists
         return;
     }
+
+    // ---- S == 1: the codeword goes into the LDS space of the (now dead) unsorted step list
+    uint8_t *y = reinterpret_cast<uint8_t *>(steps);
+    if (fast) {
+        constexpr int U = 4;
+        const int nq = n >> 3;
+        const uint64_t *er64 = reinterpret_cast<const uint64_t *>(er);
+        const uint64_t *sy64 = reinterpret_cast<const uint64_t *>(sy);
+        for (int q0 = 0; q0 < nq; q0 += kWave * U) {
+            uint64_t ew[U], sw[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int q = q0 + u * kWave + lane;
+                ew[u] = (er && q < nq) ? er64[q] : 0ull;
+                sw[u] = (q < nq && q * 8 < a.in_rows) ? sy64[q] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int q = q0 + u * kWave + lane;
+                if (q < nq) {
+                    uint64_t keep = 0;  // 0xFF in every byte that was received
+#pragma unroll
+                    for (int b = 0; b < 8; b++) {
+                        const bool e = er ? (((ew[u] >> (8 * b)) & 0xFFull) != 0) : (q * 8 + b >= a.in_rows);
+                        if (!e) keep |= 0xFFull << (8 * b);
+                    }
+                    *reinterpret_cast<uint64_t *>(y + q * 8) = sw[u] & keep;
+                }
+            }
+        }
+    } else {
+        for (int j = lane; j < n; j += kWave) {
+            const bool e = er ? (er[j] != 0) : (j >= a.in_rows);
+            y[j] = (e || j >= a.in_rows) ? (uint8_t)0 : sy[j];
+        }
+    }
+    wave_sync();
 
     // ---- S == 1: apply the steps on the LDS-resident codeword, one lane per step, level by level.
     //      y(e) = inv(H(i,e)) * sum_{j != e} H(i,j) y(j)      (...Decoder.m:39-47)
@@ -883,11 +913,14 @@ static PeelLds make_peel_lds(const DevCode &cd, bool fused, int wpb)
     L.ex = off; if (fused) off += 512;
     L.wave0 = off;
     int w = 0;
-    L.st = w; w += align_up(std::max(2 * cd.n, 4 * (cd.m + 2)), 16);
-    L.y = w; if (fused) w += align_up(cd.n, 16);
-    L.steps = w; w += align_up(4 * cd.m, 16);
+    // st (u16 per symbol) dies after the peel: its space then holds the level offsets and the sorted steps;
+    // steps (unsorted) dies after the sort: for S == 1 its space then holds the codeword
+    const int lvl_bytes = align_up(4 * (cd.m + 2), 16);
+    L.st = w; w += std::max(align_up(2 * cd.n, 16), lvl_bytes + align_up(4 * cd.m, 16));
+    L.sorted = L.st + lvl_bytes;
+    L.y = 0;
+    L.steps = w; w += align_up(std::max(4 * cd.m, fused ? cd.n : 0), 16);
     L.slvl = w; w += align_up(2 * cd.m, 16);
-    L.sorted = w; w += align_up(4 * cd.m, 16);
     L.wave_stride = w;
     L.total = off + wpb * w;
     return L;
@@ -1066,11 +1099,20 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     const bool use_scatter = plan.lpr > 0;
     if (d.inplace && !use_scatter) return set_error(ctx, LDPC_AMD_EUNSUP, "in-place decode needs the scatter kernel");
 
-    // workgroup shape: as many frames per workgroup as fit comfortably in LDS
-    int wpb = 4;
-    PeelLds L = make_peel_lds(cd, fused, wpb);
-    while (wpb > 1 && L.total > 96 * 1024) { wpb >>= 1; L = make_peel_lds(cd, fused, wpb); }
+    // workgroup shape: the peel is latency bound (serial solve chain per frame), so pick the frames-per-workgroup
+    // that puts the most wavefronts on a CU within its 160 KB of LDS (the code tables are shared by a workgroup)
+    int wpb = 1;
+    PeelLds L = make_peel_lds(cd, fused, 1);
     if (L.total > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "code too large for LDS (%d bytes)", L.total);
+    {
+        int best = 0;
+        for (int w = 1; w <= 16; w++) {
+            const PeelLds t = make_peel_lds(cd, fused, w);
+            if (t.total > kLdsMax) break;
+            const int waves = std::min(32, (kLdsMax / t.total) * w);
+            if (waves > best) { best = waves; wpb = w; L = t; }
+        }
+    }
 
     const int64_t nf = d.nframes;
     int rc;
