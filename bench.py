@@ -116,10 +116,17 @@ def run_gpu(args, rank, world, local_rank):
     import torch.distributed as dist
     from ldpc_erasure_codes_amd import api, codes, sharding
 
+    # LDPC_BENCH_BACKEND=gloo is only for rehearsing the N > 1 launch path on a box with fewer GPUs than ranks
+    backend = os.environ.get("LDPC_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     ctx = api.Context(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # torch events and our kernels share one stream

@@ -38,6 +38,9 @@ def gather_status(words, counts=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return [words]
     world = dist.get_world_size()
+    dev = words.device
+    if dist.get_backend() == "gloo":  # CPU rehearsals of the multi-GPU path: gloo gathers host tensors
+        words = words.cpu()
     if counts is None:
         c = torch.tensor([words.shape[1]], dtype=torch.int64, device=words.device)
         allc = [torch.zeros_like(c) for _ in range(world)]
@@ -48,7 +51,7 @@ def gather_status(words, counts=None):
     padded[:, :words.shape[1]] = words
     gathered = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(gathered, padded)
-    return [gathered[r][:, :counts[r]] for r in range(world)]
+    return [gathered[r][:, :counts[r]].to(dev) for r in range(world)]
 
 
 def max_over_ranks(seconds, device=None):
@@ -57,6 +60,6 @@ def max_over_ranks(seconds, device=None):
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(seconds)
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    t = torch.tensor([seconds], dtype=torch.float64, device=None if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
