@@ -603,6 +603,7 @@ struct ScatterArgs {
     int in_rows;              // rows per input frame: n (decode) or k (encode: rows >= k are the unknowns)
     int static_sched;         // encode: the code's static schedule / lists are used for every frame
     int inplace;              // out == sym: received rows stay where they are, only erased rows are written
+    int xcd_map;              // place the slices of a frame on one XCD
     int tcap;                 // tier 1 handles frames with at most tcap steps (its LDS holds tcap accumulators)
     const int32_t *big_list;  // tier 2: [0] = count, [1..] ids of the frames with more steps; nullptr in tier 1
     int lds_acc, lds_tgt, lds_invc, lds_lvlend, lds_solved, lds_mt, lds_soc;
@@ -806,8 +807,19 @@ template <int LPR, int R, bool NT, int WPE>
 __global__ __launch_bounds__(1024, WPE) void ldpc_scatter_kernel(ScatterArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int64_t f = blockIdx.x / a.nslices;
-    const int sl = (int)(blockIdx.x % a.nslices);
+    // Optional XCD-aware placement (LDPC_AMD_SCATTER_XCD=1): workgroups are dealt round-robin over the 8 XCDs, so
+    // block b = 8 i + x handling slice i % nslices of frame (i / nslices) * 8 + x keeps the slices of a frame (which
+    // read the same per-frame lists) on one L2.  Speed only; measured neutral, so off by default.
+    int64_t f;
+    int sl;
+    if (a.xcd_map && (a.nframes & 7) == 0) {
+        const int64_t x = blockIdx.x & 7, i = blockIdx.x >> 3;
+        f = (i / a.nslices) * 8 + x;
+        sl = (int)(i % a.nslices);
+    } else {
+        f = blockIdx.x / a.nslices;
+        sl = (int)(blockIdx.x % a.nslices);
+    }
     if (!a.static_sched && (int)a.sched_hdr[2 * f] > a.tcap) return;
     scatter_frame<LPR, R, NT>(a, smem, f, sl);
 }
@@ -1016,6 +1028,8 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
     constexpr int THREADS = (LPR >= 8) ? 1024 : (LPR >= 2 ? 512 : 256);
     const char *env_nt = getenv("LDPC_AMD_SCATTER_NT");
     const bool nt = env_nt ? atoi(env_nt) != 0 : true;
+    const char *env_x = getenv("LDPC_AMD_SCATTER_XCD");
+    sa.xcd_map = env_x ? atoi(env_x) : 0;  // measured: no gain (3.25 vs 3.23 ms), kept as a knob
     const dim3 grid((unsigned)(sa.nframes * sa.nslices));
     // tier 1
     sa.tcap = p.tcap; sa.big_list = nullptr;

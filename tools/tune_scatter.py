@@ -53,10 +53,12 @@ def main():
         "scatter 2tier nt R1": {"LDPC_AMD_SCATTER_NT": "1", "LDPC_AMD_SCATTER_R": "1"},
         "scatter 2tier nt R2": {"LDPC_AMD_SCATTER_NT": "1", "LDPC_AMD_SCATTER_R": "2"},
         "scatter 2tier nt R4": {"LDPC_AMD_SCATTER_NT": "1", "LDPC_AMD_SCATTER_R": "4"},
+        "xcd0": {"LDPC_AMD_SCATTER_XCD": "0"},
+        "xcd1": {"LDPC_AMD_SCATTER_XCD": "1"},
     }
     if args.variants:
         variants = {k: v for k, v in variants.items() if any(x in k for x in args.variants.split(","))}
-    knobs = ["LDPC_AMD_APPLY", "LDPC_AMD_SCATTER_TIERS", "LDPC_AMD_SCATTER_NT", "LDPC_AMD_SCATTER_R"]
+    knobs = ["LDPC_AMD_APPLY", "LDPC_AMD_SCATTER_TIERS", "LDPC_AMD_SCATTER_NT", "LDPC_AMD_SCATTER_R", "LDPC_AMD_SCATTER_XCD"]
     times = {name: {"peel": [], "apply": []} for name in variants}
     ctx.set_profiling(True)
     for rnd in range(args.rounds + 1):
