@@ -132,6 +132,12 @@ int ldpc_amd_synth_source(ldpc_amd_ctx *ctx, uint64_t seed, int64_t frame0, int6
 int ldpc_amd_synth_erasures_uniform(ldpc_amd_ctx *ctx, uint64_t seed, int64_t frame0, int64_t nframes, int n,
                                     double per, uint8_t *d_erased);
 
+/* Gilbert-Elliott bursty channel of Matlab/Bursty_Error_Channel_Model_Generator.m:12-47 (good state erases w.p.
+ * alpha, bad w.p. beta, P(good->bad) = 0.1/good_transition_bias, P(bad->good) = 0.1), the chain state carried across
+ * symbols and frames from global symbol 0 (Matlab/ErasureCodes_NonBinaryLDPCSim.m:163,191-198). */
+int ldpc_amd_synth_erasures_bursty(ldpc_amd_ctx *ctx, uint64_t seed, int64_t frame0, int64_t nframes, int n,
+                                   double alpha, double beta, double good_transition_bias, uint8_t *d_erased);
+
 /* ---- drop-in for the three OpenCL kernels of the FPGA harness ------------------------------------
  * The reference host sets 6 + 2 + 3 kernel arguments and enqueues three tasks
  * (OpenCL/host/src/main.cpp:578-604, 617-626).  These three calls take the same scalars in the same order.

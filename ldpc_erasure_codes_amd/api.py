@@ -33,7 +33,7 @@ EXPORTS = [
     "ldpc_amd_code_params", "ldpc_amd_load_builtin_code", "ldpc_amd_register_code", "ldpc_amd_code_info",
     "ldpc_amd_code_csr", "ldpc_amd_decode_batch", "ldpc_amd_encode_batch", "ldpc_amd_rs_create",
     "ldpc_amd_rs_generator", "ldpc_amd_rs_encode_batch", "ldpc_amd_rs_decode_batch", "ldpc_amd_synth_source",
-    "ldpc_amd_synth_erasures_uniform", "ldpc_amd_data_in", "ldpc_amd_ldpc_erasure_decoder", "ldpc_amd_data_out",
+    "ldpc_amd_synth_erasures_uniform", "ldpc_amd_synth_erasures_bursty", "ldpc_amd_data_in", "ldpc_amd_ldpc_erasure_decoder", "ldpc_amd_data_out",
     "ldpc_amd_set_profiling", "ldpc_amd_get_profile", "ldpc_amd_selftest", "ldpc_amd_gf_tables", "ldpc_amd_version",
 ]
 
@@ -86,6 +86,7 @@ def load_library():
     L.ldpc_amd_rs_decode_batch.argtypes = [vp, i32, i32, i64, vp, vp, vp, C.c_uint]
     L.ldpc_amd_synth_source.argtypes = [vp, u64, i64, i64, i32, i32, vp]
     L.ldpc_amd_synth_erasures_uniform.argtypes = [vp, u64, i64, i64, i32, C.c_double, vp]
+    L.ldpc_amd_synth_erasures_bursty.argtypes = [vp, u64, i64, i64, i32, C.c_double, C.c_double, C.c_double, vp]
     L.ldpc_amd_data_in.argtypes = [vp, vp, C.c_ushort, i32, i32, i32, C.c_long]
     L.ldpc_amd_ldpc_erasure_decoder.argtypes = [vp, C.c_short, i32]
     L.ldpc_amd_data_out.argtypes = [vp, vp, i32, C.c_long, C.POINTER(ErrorType)]
@@ -303,6 +304,11 @@ class Context:
     def synth_erasures_uniform(self, seed, frame0, nframes, n, per, out):
         self._check(self._L.ldpc_amd_synth_erasures_uniform(self._h, seed, frame0, nframes, n, float(per), _ptr(out)),
                     "synth_erasures_uniform")
+        return out
+
+    def synth_erasures_bursty(self, seed, frame0, nframes, n, alpha, beta, bias, out):
+        self._check(self._L.ldpc_amd_synth_erasures_bursty(self._h, seed, frame0, nframes, n, float(alpha), float(beta),
+                                                           float(bias), _ptr(out)), "synth_erasures_bursty")
         return out
 
     # -- FPGA harness trio (OpenCL/host/src/main.cpp:578-626)

@@ -642,6 +642,15 @@ int ldpc_amd_synth_erasures_uniform(ldpc_amd_ctx *ctx, uint64_t seed, int64_t fr
     return launch_synth_erasures(ctx, seed, LDPC_SYNTH_STREAM_ERASE, frame0 * n, nframes * n, ldpc_synth_threshold(per), d_erased);
 }
 
+int ldpc_amd_synth_erasures_bursty(ldpc_amd_ctx *ctx, uint64_t seed, int64_t frame0, int64_t nframes, int n,
+                                   double alpha, double beta, double good_transition_bias, uint8_t *d_erased)
+{
+    if (!ctx || !d_erased || nframes < 0 || frame0 < 0 || n < 1 || good_transition_bias <= 0)
+        return ctx ? set_error(ctx, LDPC_AMD_EINVAL, "bad argument") : LDPC_AMD_EINVAL;
+    LDPC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch_synth_bursty(ctx, seed, frame0 * n, (frame0 + nframes) * n, alpha, beta, good_transition_bias, d_erased);
+}
+
 // ---- FPGA harness drop-in (three kernels of OpenCL/host/src/main.cpp:578-626) ---------------------------
 static int fpga_code(ldpc_amd_ctx *ctx, int code_ind)
 {

@@ -132,6 +132,8 @@ int launch_selftest(ldpc_amd_ctx *ctx);
 int launch_synth_source(ldpc_amd_ctx *ctx, uint64_t seed, int64_t frame0, int64_t nframes, int k, int S, uint8_t *d);
 int launch_synth_erasures(ldpc_amd_ctx *ctx, uint64_t seed, uint32_t stream_id, int64_t first, int64_t count,
                           uint64_t thresh, uint8_t *d);
+int launch_synth_bursty(ldpc_amd_ctx *ctx, uint64_t seed, int64_t first, int64_t count, double alpha, double beta,
+                        double bias, uint8_t *d);
 int launch_synth_fpga(ldpc_amd_ctx *ctx, uint32_t seed, int64_t count, int per64, uint8_t *d);
 int launch_rs_decode(ldpc_amd_ctx *ctx, const HostRs &rs, int S, int64_t nblocks, const uint16_t *idx,
                      const uint8_t *val, uint8_t *msg);

@@ -863,6 +863,84 @@ __global__ void synth_bernoulli_kernel(uint64_t seed, uint32_t stream, uint64_t 
         dst[i] = (uint8_t)ldpc_synth_bernoulli(seed, stream, base + i, thresh);
 }
 
+// Gilbert-Elliott channel (Matlab/Bursty_Error_Channel_Model_Generator.m:12-47) as a parallel scan.  The chain is
+// sequential in the reference (state carried across symbols and frames, ErasureCodes_NonBinaryLDPCSim.m:163,192);
+// a step is a function {good, bad} -> {good, bad} fixed by its transition draw, and functions compose
+// associatively: pass 1 composes 64 steps per thread and 256 threads per block, pass 2 scans the block functions,
+// pass 3 replays every segment from its now known entry state and writes the flags.
+// A function is 2 bits: bit s = next state when entered in state s.
+struct GeParams {
+    uint64_t seed, count, first;   // symbols [0, count) are simulated, flags of [first, count) are written
+    uint64_t ta, tb, t10, t01;     // thresholds: erase in good / bad state, good->bad, bad->good
+};
+constexpr int kGeSeg = 64;
+
+__device__ __forceinline__ uint32_t ge_step_fn(const GeParams &p, uint64_t i)
+{
+    const uint64_t r2 = ldpc_synth_u32(p.seed, LDPC_SYNTH_STREAM_BURST_S, i);
+    const uint32_t f0 = (r2 < p.t10) ? 1u : 0u;   // in good: go bad?
+    const uint32_t f1 = (r2 < p.t01) ? 0u : 1u;   // in bad: go good?
+    return f0 | (f1 << 1);
+}
+__device__ __forceinline__ uint32_t ge_compose(uint32_t first, uint32_t then)
+{   // (then o first)(s) = then(first(s))
+    const uint32_t a = (then >> (first & 1u)) & 1u, b = (then >> ((first >> 1) & 1u)) & 1u;
+    return a | (b << 1);
+}
+
+__global__ __launch_bounds__(256) void ge_block_fn_kernel(GeParams p, uint32_t *blockfn)
+{
+    __shared__ uint32_t fn[256];
+    const uint64_t base = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * kGeSeg;
+    uint32_t f = 2u;  // identity: 0 -> 0, 1 -> 1
+    for (int t = 0; t < kGeSeg; t++)
+        if (base + t < p.count) f = ge_compose(f, ge_step_fn(p, base + t));
+    fn[threadIdx.x] = f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t g = 2u;
+        for (int t = 0; t < 256; t++) g = ge_compose(g, fn[t]);
+        blockfn[blockIdx.x] = g;
+    }
+}
+
+__global__ void ge_scan_kernel(uint32_t nblocks, const uint32_t *blockfn, uint8_t *entry)
+{
+    if (blockIdx.x || threadIdx.x) return;
+    uint32_t s = 0;  // next_state = 0 before the first symbol (ErasureCodes_NonBinaryLDPCSim.m:163)
+    for (uint32_t b = 0; b < nblocks; b++) {
+        entry[b] = (uint8_t)s;
+        s = (blockfn[b] >> s) & 1u;
+    }
+}
+
+__global__ __launch_bounds__(256) void ge_write_kernel(GeParams p, const uint8_t *entry, uint8_t *dst)
+{
+    __shared__ uint32_t fn[256];
+    __shared__ uint8_t st0[256];
+    const uint64_t base = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * kGeSeg;
+    uint32_t f = 2u;
+    for (int t = 0; t < kGeSeg; t++)
+        if (base + t < p.count) f = ge_compose(f, ge_step_fn(p, base + t));
+    fn[threadIdx.x] = f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t s = entry[blockIdx.x];
+        for (int t = 0; t < 256; t++) { st0[t] = (uint8_t)s; s = (fn[t] >> s) & 1u; }
+    }
+    __syncthreads();
+    uint32_t s = st0[threadIdx.x];
+    for (int t = 0; t < kGeSeg; t++) {
+        const uint64_t i = base + t;
+        if (i >= p.count) break;
+        if (i >= p.first) {
+            const uint64_t r1 = ldpc_synth_u32(p.seed, LDPC_SYNTH_STREAM_BURST_E, i);
+            dst[i - p.first] = (uint8_t)(r1 < (s ? p.tb : p.ta));
+        }
+        s = (ge_step_fn(p, i) >> s) & 1u;
+    }
+}
+
 // erasure flags of the FPGA source kernel: threefry4x32-20, key {1, seed}, counter = symbol index + 1
 // (OpenCL/device/ldpc_erasure_decoder_top.cl:74-75,96-110; rule restated in include/ldpc_erasure_amd_synth.h)
 __global__ void synth_fpga_kernel(uint32_t seed, uint64_t count, int per64, uint8_t *dst)
@@ -1344,6 +1422,27 @@ int launch_synth_source(ldpc_amd_ctx *ctx, uint64_t seed, int64_t frame0, int64_
     const uint64_t words = (count + 3) / 4;
     const int grid = (int)std::min<uint64_t>((words + 255) / 256, 16384);
     hipLaunchKernelGGL(synth_bytes_kernel, dim3(grid), dim3(256), 0, ctx->stream, seed, (uint32_t)LDPC_SYNTH_STREAM_SOURCE, base, count, d);
+    LDPC_HIP_TRY(ctx, hipGetLastError());
+    return LDPC_AMD_OK;
+}
+
+int launch_synth_bursty(ldpc_amd_ctx *ctx, uint64_t seed, int64_t first, int64_t count, double alpha, double beta,
+                        double bias, uint8_t *d)
+{
+    if (count <= first) return LDPC_AMD_OK;
+    GeParams p{};
+    p.seed = seed; p.count = (uint64_t)count; p.first = (uint64_t)first;
+    const double transition = 0.1;  // Bursty_Error_Channel_Model_Generator.m:16
+    p.ta = ldpc_synth_threshold(alpha); p.tb = ldpc_synth_threshold(beta);
+    p.t10 = ldpc_synth_threshold(transition / bias); p.t01 = ldpc_synth_threshold(transition);
+    const uint32_t nblocks = (uint32_t)((count + 256 * kGeSeg - 1) / (256 * kGeSeg));
+    int rc = scratch_reserve(ctx, ctx->rsws, (size_t)nblocks * 5 + 64);
+    if (rc) return rc;
+    uint32_t *blockfn = (uint32_t *)ctx->rsws.p;
+    uint8_t *entry = (uint8_t *)(blockfn + nblocks);
+    hipLaunchKernelGGL(ge_block_fn_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, p, blockfn);
+    hipLaunchKernelGGL(ge_scan_kernel, dim3(1), dim3(1), 0, ctx->stream, nblocks, (const uint32_t *)blockfn, entry);
+    hipLaunchKernelGGL(ge_write_kernel, dim3(nblocks), dim3(256), 0, ctx->stream, p, (const uint8_t *)entry, d);
     LDPC_HIP_TRY(ctx, hipGetLastError());
     return LDPC_AMD_OK;
 }

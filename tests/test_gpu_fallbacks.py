@@ -74,3 +74,18 @@ def test_tier2_frames_and_wide_packets(ctx, oracle, code_a):
     st = check_packets(ctx, oracle, code_a, h, 1024, [0.16, 0.17, 0.10], 330)
     assert (st == 0).all()
     check_packets(ctx, oracle, code_a, h, 4096, [0.12, 0.2], 340)
+
+
+def test_device_bursty_channel_equals_sequential_chain(ctx, oracle):
+    """Parallel-scan Gilbert-Elliott generator == the oracle's literal sequential chain
+    (Matlab/Bursty_Error_Channel_Model_Generator.m:12-47), incl. a start in the middle of the stream."""
+    torch = pytest.importorskip("torch")
+    n = 2040
+    for frame0, nframes, alpha, beta in ((0, 40, 0.1, 0.4), (7, 33, 0.13, 0.8), (0, 1, 0.0, 1.0)):
+        d = torch.empty((nframes, n), dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        ctx.synth_erasures_bursty(31, frame0, nframes, n, alpha, beta, 10.0, d)
+        ctx.synchronize()
+        want = oracle.synth_erasures_bursty(31, frame0, nframes, n, alpha, beta, 10.0)
+        assert np.array_equal(d.cpu().numpy(), want)
+        assert np.array_equal(want, synth.erasures_bursty(31, frame0, nframes, n, alpha, beta, 10.0))
