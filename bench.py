@@ -37,7 +37,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 SEED_SRC, SEED_ERA = 20261004, 20261005
 
 
-SCATTER_KERNEL = "ldpc_scatter_kernel<16, 2, true, 8>"  # LPR=16 (256-byte row pieces), 2 pieces in flight, nt, 8 waves/SIMD
+SCATTER_KERNEL = "ldpc_scatter_kernel<16, 2, true, 8, false>"  # LPR=16 (256-byte row pieces), 2 pieces in flight, nt, 8 waves/SIMD, out of place
 PEEL_S1_KERNEL = "ldpc_peel_kernel<16, true>"
 
 

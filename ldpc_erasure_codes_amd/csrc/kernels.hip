@@ -207,8 +207,6 @@ struct PeelArgs {
     uint16_t *sched_lvlend; // [nframes][m+1]
     int32_t *big_list;      // [0] = count, [1..] frames with more than tcap steps (scatter tier 2), or nullptr
     int tcap;
-    // packet path, scatter form: for every source symbol j the (slot, coefficient) pairs of the steps it feeds
-    uint32_t *src_pad;      // [nframes][n][1 << cdw_shift]   slot | coef << 16, or 0xFFFFFFFF   (or nullptr)
     // ML hand-off
     int32_t *ml_list;       // [0] = count, [1..] frame ids
     uint8_t *ml_state;      // [slot][n]  1 = still erased
@@ -358,44 +356,6 @@ __global__ __launch_bounds__(1024) void ldpc_peel_kernel(PeelArgs a)
         uint16_t *gl = a.sched_lvlend + f * (m + 1);
         for (int i = lane; i <= maxlvl; i += kWave) gl[i] = (uint16_t)lvlend[i];
         LDPC_STAMP(4);  // schedule write-out
-        if (!a.src_pad) return;
-        // Transpose the used checks: symbol j -> (slot of the step it feeds, H(check, j)) for every USED check that
-        // contains j, except the check that solves j itself.  Lane = symbol: H's static column lists are read
-        // coalesced from L2, the check -> slot table sits in LDS, and each lane writes its own contiguous run.
-        uint16_t *soc = slvl;  // slvl is dead after the sort: reuse it as check -> slot (0xFFFF = unused)
-        for (int i = lane; i < m; i += kWave) soc[i] = 0xFFFFu;
-        wave_sync();
-        for (int s = lane; s < nsteps; s += kWave) soc[sorted[s] & 0xFFFFu] = (uint16_t)s;
-        wave_sync();
-        // One lane per entry of H's column lists (padded to cdwp = 2^sh entries per symbol): coalesced 256-byte
-        // reads and writes; unused entries become 0xFFFFFFFF and are skipped by the scatter kernel.
-        const int sh = cd.cdw_shift, cdwp = 1 << sh;
-        const uint32_t *cellp = cd.cell;
-        uint32_t *gp = a.src_pad + f * (int64_t)n * cdwp;
-        const int words = n << sh;
-        // Batches of 16 entries per lane, each step done for the whole batch before the next one (independent L2
-        // loads, then independent LDS reads) -- per-entry dependent chains made this loop latency bound.
-        constexpr int U = 16;
-        for (int w0 = 0; w0 < words; w0 += kWave * U) {
-            uint32_t ce[U], sl[U], tg[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int w = w0 + u * kWave + lane;
-                ce[u] = (w < words) ? cellp[w] : 0xFFFFFFFFu;
-            }
-#pragma unroll
-            for (int u = 0; u < U; u++) sl[u] = soc[ce[u] == 0xFFFFFFFFu ? 0u : (ce[u] & 0xFFFFu)];
-#pragma unroll
-            for (int u = 0; u < U; u++) tg[u] = sorted[sl[u] == 0xFFFFu ? 0u : sl[u]] >> 16;
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const int w = w0 + u * kWave + lane;
-                const bool valid = (ce[u] != 0xFFFFFFFFu) && (sl[u] != 0xFFFFu) && (tg[u] != (uint32_t)(w >> sh));
-                // whole 256-byte lines are written (pad = 0xFFFFFFFF): partial-line stores were store-issue bound
-                if (w < words) gp[w] = valid ? (sl[u] | (ce[u] & 0x00FF0000u)) : 0xFFFFFFFFu;
-            }
-        }
-        LDPC_STAMP(5);  // per-source lists
         return;
     }
 
@@ -599,14 +559,13 @@ struct ScatterArgs {
     const uint32_t *sched_hdr;
     const uint32_t *sched_steps;
     const uint16_t *sched_lvlend;
-    const uint32_t *src_pad;
     int in_rows;              // rows per input frame: n (decode) or k (encode: rows >= k are the unknowns)
     int static_sched;         // encode: the code's static schedule / lists are used for every frame
     int inplace;              // out == sym: received rows stay where they are, only erased rows are written
     int xcd_map;              // place the slices of a frame on one XCD
     int tcap;                 // tier 1 handles frames with at most tcap steps (its LDS holds tcap accumulators)
     const int32_t *big_list;  // tier 2: [0] = count, [1..] ids of the frames with more steps; nullptr in tier 1
-    int lds_acc, lds_tgt, lds_invc, lds_lvlend, lds_solved, lds_mt, lds_soc;
+    int lds_acc, lds_tgt, lds_invc, lds_lvlend, lds_solved, lds_mt, lds_soc, lds_chk;
 };
 
 __device__ __forceinline__ MulTab lds_multab(const uint32_t *mt, uint32_t c)
@@ -653,7 +612,7 @@ __device__ __forceinline__ void stream_store16(uint8_t *p, const U4 &v)
     }
 }
 
-template <int LPR, int R, bool NT>
+template <int LPR, int R, bool NT, bool INPLACE>
 __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned char *smem, const int64_t f, const int sl)
 {
     constexpr int RPW = 64 / LPR;              // row pieces per wave instruction
@@ -673,12 +632,14 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     uint32_t *solved = reinterpret_cast<uint32_t *>(smem + a.lds_solved);
     uint32_t *mt = reinterpret_cast<uint32_t *>(smem + a.lds_mt);
     uint8_t *rk = smem + a.lds_soc;  // row kinds, [n]
+    uint16_t *soc = reinterpret_cast<uint16_t *>(smem + a.lds_chk);  // check -> slot of the step that uses it, 0xFFFF
 
     const int nsteps = a.static_sched ? cd.m : (int)a.sched_hdr[2 * f];
     const int nlev = a.static_sched ? cd.enc_nlevels : (int)a.sched_hdr[2 * f + 1];
     const uint32_t *gs = a.static_sched ? cd.enc_steps : a.sched_steps + f * cd.m;
     const uint16_t *gle = a.static_sched ? cd.enc_lvlend : a.sched_lvlend + f * (cd.m + 1);
     for (int i = tid; i < (n + 31) / 32; i += nthr) solved[i] = 0;
+    for (int i = tid; i < (cd.m + 1) / 2; i += nthr) reinterpret_cast<uint32_t *>(soc)[i] = 0xFFFFFFFFu;
     for (int i = tid; i < 2048; i += nthr) mt[i] = c_mul3[i];
     for (int i = tid; i <= nlev; i += nthr) lvlend[i] = gle[i];
     for (int i = tid; i < nsteps * LPR; i += nthr) reinterpret_cast<U4 *>(acc)[i] = U4{0, 0, 0, 0};
@@ -687,6 +648,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         const uint32_t step = gs[s];
         const uint32_t row = step & 0xFFFFu, t = step >> 16;
         tgt[s] = (uint16_t)t;
+        soc[row] = (uint16_t)s;
         uint32_t ct = 1;
         for (uint32_t e = cd.row_ptr[row]; e < cd.row_ptr[row + 1]; e++) {
             const uint32_t ed = cd.edges[e];
@@ -707,7 +669,9 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
 
     const uint8_t *fin = a.sym + f * (int64_t)a.in_rows * S + (int64_t)sl * B + gl * 16;
     uint8_t *fout = a.out + f * (int64_t)n * S + (int64_t)sl * B + gl * 16;
-    const uint32_t *spad = a.static_sched ? cd.enc_src : a.src_pad + ((f * (int64_t)n) << cd.cdw_shift);
+    // H's static column lists (check | coef << 16); the encoder's are already in (slot | coef << 16) form
+    const uint32_t *spad = a.static_sched ? cd.enc_src : cd.cell;
+    const bool translate = !a.static_sched;
 
     // multiplies v into the accumulators of the steps that symbol j feeds: ew = the symbol's list, entry t held by
     // lane (t % LPR) of the group, 0xFFFFFFFF = no entry.  Every group walks the set bits of its own validity mask.
@@ -727,6 +691,19 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
                     lds_xor16(acc + (size_t)s * B + gl * 16, prod, h);
                 }
             }
+        }
+    };
+
+    // A symbol's column-list word (check | coef << 16) becomes (slot | coef << 16) if the check is used by a step of
+    // this frame -- other than the step that solves the symbol itself (own) -- and 0xFFFFFFFF otherwise: one LDS
+    // look-up per lane, no per-frame lists in HBM.
+    auto to_slots = [&](uint32_t (&ew)[KQ], uint32_t own) {
+        if (!translate) return;
+#pragma unroll
+        for (int q = 0; q < KQ; q++) {
+            const uint32_t w = ew[q];
+            const uint32_t s = soc[w == 0xFFFFFFFFu ? 0u : (w & 0xFFFFu)];
+            ew[q] = (w != 0xFFFFFFFFu && s != 0xFFFFu && s != own) ? (s | (w & 0x00FF0000u)) : 0xFFFFFFFFu;
         }
     };
 
@@ -767,7 +744,8 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const int j = j0 + r * RPW + g;
-                if (cur.kind[r] == 2 || (cur.kind[r] == 1 && !a.inplace)) stream_store16<NT>(fout + (int64_t)j * S, cur.v[r]);
+                if (cur.kind[r] == 2 || (cur.kind[r] == 1 && !INPLACE)) stream_store16<NT>(fout + (int64_t)j * S, cur.v[r]);
+                to_slots(cur.ew[r], 0xFFFFu);
                 scatter(cur.v[r], cur.ew[r]);
             }
             cur = nxt;
@@ -795,6 +773,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
                     if (idx < cdw) ew[q] = spad[((int64_t)t << cd.cdw_shift) + idx];
                 }
             }
+            to_slots(ew, (s < s1) ? (uint32_t)s : 0xFFFFu);
             scatter(val, ew);
         }
         __syncthreads();
@@ -803,7 +782,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
 
 // Tier 1: one workgroup per (frame, slice); frames with more than tcap steps are left to tier 2.
 // WPE = waves per SIMD the register allocation must allow (8 -> two 1024-thread workgroups per CU).
-template <int LPR, int R, bool NT, int WPE>
+template <int LPR, int R, bool NT, int WPE, bool INPLACE>
 __global__ __launch_bounds__(1024, WPE) void ldpc_scatter_kernel(ScatterArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -821,18 +800,18 @@ __global__ __launch_bounds__(1024, WPE) void ldpc_scatter_kernel(ScatterArgs a)
         sl = (int)(blockIdx.x % a.nslices);
     }
     if (!a.static_sched && (int)a.sched_hdr[2 * f] > a.tcap) return;
-    scatter_frame<LPR, R, NT>(a, smem, f, sl);
+    scatter_frame<LPR, R, NT, INPLACE>(a, smem, f, sl);
 }
 
 // Tier 2: the few frames with many steps (LDS sized for m accumulators), grid-stride over the compacted list.
-template <int LPR, int R, bool NT>
+template <int LPR, int R, bool NT, bool INPLACE>
 __global__ __launch_bounds__(1024) void ldpc_scatter_big_kernel(ScatterArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int64_t items = (int64_t)a.big_list[0] * a.nslices;
     for (int64_t it = blockIdx.x; it < items; it += gridDim.x) {
         __syncthreads();
-        scatter_frame<LPR, R, NT>(a, smem, a.big_list[1 + it / a.nslices], (int)(it % a.nslices));
+        scatter_frame<LPR, R, NT, INPLACE>(a, smem, a.big_list[1 + it / a.nslices], (int)(it % a.nslices));
     }
 }
 
@@ -1049,7 +1028,7 @@ struct ScatterPlan {
     int tcap = 0;       // tier 1 handles frames with <= tcap steps
     bool two_tier = false;
     int lds1 = 0, lds2 = 0;                       // dynamic LDS bytes of tier 1 / tier 2
-    int o_tgt = 0, o_invc = 0, o_lvl = 0, o_sol = 0, o_mt = 0, o_soc = 0;  // offsets behind the accumulators (relative)
+    int o_tgt = 0, o_invc = 0, o_lvl = 0, o_sol = 0, o_mt = 0, o_soc = 0, o_chk = 0;  // offsets behind the accumulators (relative)
 };
 
 static int scatter_tail_bytes(const DevCode &cd, ScatterPlan &p)
@@ -1061,6 +1040,7 @@ static int scatter_tail_bytes(const DevCode &cd, ScatterPlan &p)
     p.o_sol = off; off += align_up((cd.n + 31) / 32 * 4, 16);
     p.o_mt = off; off += 8192;
     p.o_soc = off; off += align_up(cd.n, 16);  // row kinds
+    p.o_chk = off; off += align_up(2 * (cd.m + 2), 16);  // check -> slot
     return off;
 }
 
@@ -1097,7 +1077,7 @@ static void scatter_set_lds(ScatterArgs &sa, const ScatterPlan &p, int nacc)
     const int base = align_up(nacc * 16 * p.lpr, 16);
     sa.lds_acc = 0;
     sa.lds_tgt = base + p.o_tgt; sa.lds_invc = base + p.o_invc; sa.lds_lvlend = base + p.o_lvl;
-    sa.lds_solved = base + p.o_sol; sa.lds_mt = base + p.o_mt; sa.lds_soc = base + p.o_soc;
+    sa.lds_solved = base + p.o_sol; sa.lds_mt = base + p.o_mt; sa.lds_soc = base + p.o_soc; sa.lds_chk = base + p.o_chk;
 }
 
 template <int LPR, int R>
@@ -1112,29 +1092,36 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
     // tier 1
     sa.tcap = p.tcap; sa.big_list = nullptr;
     scatter_set_lds(sa, p, p.tcap);
-#define LDPC_SCATTER_T1(NTV, WPE)                                                                          \
+#define LDPC_SCATTER_T1(NTV, WPE, IPV)                                                                         \
     {                                                                                                        \
-        auto kfn = ldpc_scatter_kernel<LPR, R, NTV, WPE>;                                                    \
+        auto kfn = ldpc_scatter_kernel<LPR, R, NTV, WPE, IPV>;                                                    \
         LDPC_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                           \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, p.lds1));          \
         hipLaunchKernelGGL(kfn, grid, dim3(THREADS), (size_t)p.lds1, ctx->stream, sa);                       \
     }
-    if (p.two_tier) { if (nt) LDPC_SCATTER_T1(true, 8) else LDPC_SCATTER_T1(false, 8) }
-    else { if (nt) LDPC_SCATTER_T1(true, 4) else LDPC_SCATTER_T1(false, 4) }
+    const bool ip = sa.inplace != 0;
+    if (p.two_tier) {
+        if (ip) { if (nt) LDPC_SCATTER_T1(true, 8, true) else LDPC_SCATTER_T1(false, 8, true) }
+        else { if (nt) LDPC_SCATTER_T1(true, 8, false) else LDPC_SCATTER_T1(false, 8, false) }
+    } else {
+        if (ip) { if (nt) LDPC_SCATTER_T1(true, 4, true) else LDPC_SCATTER_T1(false, 4, true) }
+        else { if (nt) LDPC_SCATTER_T1(true, 4, false) else LDPC_SCATTER_T1(false, 4, false) }
+    }
 #undef LDPC_SCATTER_T1
     LDPC_HIP_TRY(ctx, hipGetLastError());
     if (p.two_tier) {
         sa.tcap = sa.code.m; sa.big_list = big_list;
         scatter_set_lds(sa, p, sa.code.m);
         const dim3 g2((unsigned)std::min<int64_t>(sa.nframes * sa.nslices, ctx->sm_count));
-#define LDPC_SCATTER_T2(NTV)                                                                               \
+#define LDPC_SCATTER_T2(NTV, IPV)                                                                            \
     {                                                                                                        \
-        auto kfn = ldpc_scatter_big_kernel<LPR, R, NTV>;                                                     \
+        auto kfn = ldpc_scatter_big_kernel<LPR, R, NTV, IPV>;                                                     \
         LDPC_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                           \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, p.lds2));          \
         hipLaunchKernelGGL(kfn, g2, dim3(THREADS), (size_t)p.lds2, ctx->stream, sa);                         \
     }
-        if (nt) LDPC_SCATTER_T2(true) else LDPC_SCATTER_T2(false)
+        if (ip) { if (nt) LDPC_SCATTER_T2(true, true) else LDPC_SCATTER_T2(false, true) }
+        else { if (nt) LDPC_SCATTER_T2(true, false) else LDPC_SCATTER_T2(false, false) }
 #undef LDPC_SCATTER_T2
         LDPC_HIP_TRY(ctx, hipGetLastError());
     }
@@ -1233,13 +1220,10 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     } else {
         const size_t hdr = (size_t)nf * 2 * 4, st = (size_t)nf * cd.m * 4, le = (size_t)nf * (cd.m + 1) * 2;
         const size_t o1 = (hdr + 255) & ~(size_t)255, o2 = (o1 + st + 255) & ~(size_t)255;
-        const size_t o3 = (o2 + le + 255) & ~(size_t)255;
-        const size_t sp = use_scatter ? ((size_t)nf * cd.n * 4) << cd.cdw_shift : 0;
-        if ((rc = scratch_reserve(ctx, ctx->sched, o3 + sp))) return rc;
+        if ((rc = scratch_reserve(ctx, ctx->sched, o2 + le))) return rc;
         unsigned char *base = (unsigned char *)ctx->sched.p;
         pa.sched_hdr = (uint32_t *)base; pa.sched_steps = (uint32_t *)(base + o1); pa.sched_lvlend = (uint16_t *)(base + o2);
         if (use_scatter) {
-            pa.src_pad = (uint32_t *)(base + o3);
             pa.tcap = plan.tcap;
             pa.big_list = plan.two_tier ? (int32_t *)ctx->biglist.p : nullptr;
         }
@@ -1252,7 +1236,6 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             sa.code = cd; sa.S = d.S; sa.nslices = plan.nslices; sa.nframes = nf; sa.sym = d.sym; sa.erased = d.erased; sa.out = d.out;
             sa.in_rows = cd.n; sa.static_sched = 0; sa.inplace = d.inplace;
             sa.sched_hdr = pa.sched_hdr; sa.sched_steps = pa.sched_steps; sa.sched_lvlend = pa.sched_lvlend;
-            sa.src_pad = pa.src_pad;
             ev = prof_begin(ctx);
             if ((rc = launch_scatter(ctx, plan, sa, (const int32_t *)ctx->biglist.p))) return rc;
             prof_end(ctx, LDPC_AMD_PROF_APPLY, ev);
