@@ -1048,6 +1048,8 @@ static ScatterPlan plan_scatter(const DevCode &cd, int S)
 {
     ScatterPlan p;
     int B = 256;
+    const char *env_b = getenv("LDPC_AMD_SCATTER_B");  // A/B knob: bytes of every row per workgroup
+    if (env_b && (atoi(env_b) == 128 || atoi(env_b) == 64)) B = atoi(env_b);
     while (B > 16 && (S % B) != 0) B >>= 1;
     const int tail = scatter_tail_bytes(cd, p);
     while (B > 16 && cd.m * B + tail > 156 * 1024) B >>= 1;
