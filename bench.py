@@ -181,6 +181,13 @@ def run_gpu(args, rank, world, local_rank):
         ml_rate = float((res > 0).float().mean())
         sample = (sym[:2].cpu().numpy(), era[:2].cpu().numpy(), out[:2].cpu().numpy(), sw[:2].cpu().numpy())
         inplace = None
+        copy_gbps = None
+        if S >= 16:
+            # the copy rate this box reaches (same buffers, same streaming loads/stores), quoted next to
+            # the nominal HBM peak; bytes moved = read + write
+            nb = sym.numel()
+            copy_ms = ctx.copy_probe(sym, out, reps=5)
+            copy_gbps = 2.0 * nb / (copy_ms * 1e-3) / 1e9
         if S >= 16 and world == 1:
             # extension, reported separately and never as `value`: LDPC_AMD_INPLACE decodes inside the caller's frame
             # buffer and writes only the erased symbols (the reference always returns a copy)
@@ -202,12 +209,12 @@ def run_gpu(args, rank, world, local_rank):
             del buf
         del cw, sym, era, out
         torch.cuda.empty_cache()
-        return dt, prof, ok, hist, ml_rate, sample, inplace
+        return dt, prof, ok, hist, ml_rate, sample, inplace, copy_gbps
 
     result = {}
     for S in ([args.S, 1] if args.S != 1 else [1]):
         steps = args.steps if S == args.S else max(args.steps, 20)
-        dt, prof, ok, hist, ml_rate, sample, inplace = measure(S, steps, args.warmup)
+        dt, prof, ok, hist, ml_rate, sample, inplace, copy_gbps = measure(S, steps, args.warmup)
         fps = world * F * steps / dt
         kind = "apply" if S > 1 else "peel"
         kms, kcnt = prof[kind]
@@ -221,7 +228,9 @@ def run_gpu(args, rank, world, local_rank):
             "roofline": {"bound": "hbm", "kernel": SCATTER_KERNEL if S > 1 else PEEL_S1_KERNEL,
                          "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                          "traffic": pmc_traffic(SCATTER_KERNEL if S > 1 else PEEL_S1_KERNEL, F, S),
-                         "alg_bytes_per_launch": ab, "avg_launch_ms": kavg},
+                         "alg_bytes_per_launch": ab, "avg_launch_ms": kavg,
+                         "copy_kernel_GBps": copy_gbps,
+                         "frac_of_copy": (ach / copy_gbps) if copy_gbps else None},
             "sample": sample, "inplace": inplace,
         }
     ctx.close()

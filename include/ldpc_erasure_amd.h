@@ -181,6 +181,10 @@ int ldpc_amd_get_profile(ldpc_amd_ctx *ctx, double ms[LDPC_AMD_PROF_KINDS], int6
 /* Device self-test of the GF(256) primitives (packed multiply vs. table) -> 0 when all 65536 products and
  * 255 inverses agree with the host tables. */
 int ldpc_amd_selftest(ldpc_amd_ctx *ctx);
+/* Device-to-device copy of `bytes` (16-byte multiple, device pointers) with the streaming loads/stores of the packet
+ * kernel, `reps` times after one warm-up; *ms_per_copy = average device time.  The measured copy rate of the box is what
+ * SURVEY.md 8(d) asks to be quoted next to the nominal HBM peak; no reference counterpart. */
+int ldpc_amd_copy_probe(ldpc_amd_ctx *ctx, const void *src, void *dst, uint64_t bytes, int reps, double *ms_per_copy);
 /* Host copy of the GF tables the kernels use: mult[256*256], inv[256] (inv[0] = 0), either may be NULL. */
 int ldpc_amd_gf_tables(uint8_t *mult, uint8_t *inv);
 const char *ldpc_amd_version(void);

@@ -34,7 +34,7 @@ EXPORTS = [
     "ldpc_amd_code_csr", "ldpc_amd_decode_batch", "ldpc_amd_encode_batch", "ldpc_amd_rs_create",
     "ldpc_amd_rs_generator", "ldpc_amd_rs_encode_batch", "ldpc_amd_rs_decode_batch", "ldpc_amd_synth_source",
     "ldpc_amd_synth_erasures_uniform", "ldpc_amd_synth_erasures_bursty", "ldpc_amd_data_in", "ldpc_amd_ldpc_erasure_decoder", "ldpc_amd_data_out",
-    "ldpc_amd_set_profiling", "ldpc_amd_get_profile", "ldpc_amd_selftest", "ldpc_amd_gf_tables", "ldpc_amd_version",
+    "ldpc_amd_set_profiling", "ldpc_amd_get_profile", "ldpc_amd_selftest", "ldpc_amd_copy_probe", "ldpc_amd_gf_tables", "ldpc_amd_version",
 ]
 
 
@@ -93,6 +93,7 @@ def load_library():
     L.ldpc_amd_set_profiling.argtypes = [vp, i32]
     L.ldpc_amd_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
     L.ldpc_amd_selftest.argtypes = [vp]
+    L.ldpc_amd_copy_probe.argtypes = [vp, vp, vp, C.c_uint64, C.c_int, C.POINTER(C.c_double)]
     L.ldpc_amd_gf_tables.argtypes = [vp, vp]
     L.ldpc_amd_version.restype = C.c_char_p
     _lib = L
@@ -178,6 +179,13 @@ class Context:
         cnt = (C.c_int64 * 3)()
         self._check(self._L.ldpc_amd_get_profile(self._h, ms, cnt), "get_profile")
         return {name: (ms[i], cnt[i]) for i, name in enumerate(("peel", "apply", "ml"))}
+
+    def copy_probe(self, src, dst, reps=10):
+        """Average device time (ms) of one streaming copy src -> dst (torch CUDA uint8 tensors of equal size)."""
+        ms = C.c_double(0.0)
+        nbytes = src.numel() * src.element_size()
+        self._check(self._L.ldpc_amd_copy_probe(self._h, src.data_ptr(), dst.data_ptr(), nbytes & ~15, reps, C.byref(ms)), "copy_probe")
+        return ms.value
 
     def selftest(self):
         self._check(self._L.ldpc_amd_selftest(self._h), "selftest")

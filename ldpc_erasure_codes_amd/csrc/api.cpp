@@ -763,6 +763,15 @@ int ldpc_amd_selftest(ldpc_amd_ctx *ctx)
     return launch_selftest(ctx);
 }
 
+int ldpc_amd_copy_probe(ldpc_amd_ctx *ctx, const void *src, void *dst, uint64_t bytes, int reps, double *ms_per_copy)
+{
+    if (!ctx) return LDPC_AMD_EINVAL;
+    if (!src || !dst || !ms_per_copy || reps < 1 || bytes < 16 || (bytes & 15u) || ((uintptr_t)src & 15u) || ((uintptr_t)dst & 15u))
+        return set_error(ctx, LDPC_AMD_EINVAL, "copy_probe: device pointers and size must be 16-byte multiples, reps >= 1");
+    LDPC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return launch_copy_probe(ctx, (const uint8_t *)src, (uint8_t *)dst, bytes, reps, ms_per_copy);
+}
+
 int ldpc_amd_gf_tables(uint8_t *mult, uint8_t *inv)
 {
     const GfHost &g = gf_host();

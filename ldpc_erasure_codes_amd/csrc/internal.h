@@ -129,6 +129,7 @@ hipError_t upload_constants(hipStream_t s);
 int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &a);
 int launch_encode(ldpc_amd_ctx *ctx, const DevCode &code, int S, int64_t nframes, const uint8_t *src, uint8_t *cw);
 int launch_selftest(ldpc_amd_ctx *ctx);
+int launch_copy_probe(ldpc_amd_ctx *ctx, const uint8_t *src, uint8_t *dst, uint64_t bytes, int reps, double *ms);
 int launch_synth_source(ldpc_amd_ctx *ctx, uint64_t seed, int64_t frame0, int64_t nframes, int k, int S, uint8_t *d);
 int launch_synth_erasures(ldpc_amd_ctx *ctx, uint64_t seed, uint32_t stream_id, int64_t first, int64_t count,
                           uint64_t thresh, uint8_t *d);

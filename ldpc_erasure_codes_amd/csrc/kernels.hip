@@ -949,6 +949,14 @@ __global__ void selftest_kernel(int *bad)
     }
 }
 
+// Device copy probe: the same 16-byte non-temporal loads/stores the scatter kernel uses, nothing else.  bench.py runs
+// it in the same process to quote the copy rate this box reaches next to the nominal HBM peak.
+__global__ __launch_bounds__(1024) void copy_probe_kernel(const uint8_t *src, uint8_t *dst, uint64_t chunks)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < chunks; i += (uint64_t)gridDim.x * blockDim.x)
+        stream_store16<true>(dst + i * 16, stream_load16<true>(src + i * 16));
+}
+
 #include "rs_kernels.inc"
 #include "fpga_kernels.inc"
 
@@ -1259,28 +1267,42 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         ma.Spad = fused ? 16 : d.S;
         ma.ml_list = (const int32_t *)ctx->mllist.p; ma.ml_state = (const uint8_t *)ctx->mlstate.p;
         ma.out = d.out; ma.status = d.status;
-        const int maxrow = align_up(cd.m, 16) + 16;
+        const int maxrow = align_up(cd.m, 16) + 32;
+        ma.maxrow = maxrow;
         int off = 0;
-        ma.lds_colmap = off; off += align_up(2 * cd.n, 16);
+        // rlist[3][m] u32; colmap[n] u16 is only alive while rlist[1..2] are not, and shares their bytes
+        ma.lds_rlist = off; ma.lds_colmap = off + 4 * cd.m;
+        off += align_up(std::max(12 * cd.m, 4 * cd.m + 2 * cd.n), 16);
         ma.lds_elist = off; off += align_up(2 * cd.m, 16);
-        ma.lds_colv = off; off += align_up(cd.mpad, 16);
-        ma.lds_rlist = off; off += align_up(2 * cd.m, 16);
-        ma.lds_prow = off; off += maxrow + (fused ? 0 : d.S);
+        ma.lds_colv = off; off += align_up(3 * cd.mpad, 16);
+        ma.lds_perm = off; off += align_up(2 * cd.m + 2, 16);
+        ma.lds_iperm = off; off += align_up(2 * cd.m, 16);
+        ma.lds_orow = off; off += align_up(2 * cd.m, 16);
+        ma.lds_plog = off; off += align_up(cd.m, 16);
         ma.lds_mt = off; off += 8192;
-        ma.lds_misc = off; off += 64;
+        ma.lds_lg = off; off += 256;
+        ma.lds_ex = off; off += 1024;
+        ma.lds_misc = off; off += 128;
         ma.lds_A = off;
         if (off > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "ML stage: LDS need %d bytes", off);
         ma.capA = (kLdsMax - off) & ~15;
         const int total = kLdsMax;
         int grid = (int)std::min<int64_t>(nf, (int64_t)ctx->sm_count);
         const size_t perA = (size_t)cd.m * maxrow, perR = fused ? 0 : (size_t)cd.m * d.S;
-        if ((rc = scratch_reserve(ctx, ctx->mlws, (perA + perR) * grid))) return rc;
-        ma.wsA = (uint8_t *)ctx->mlws.p;
+        if ((rc = scratch_reserve(ctx, ctx->mlws, (perA + perR) * grid + 256))) return rc;
+        ma.work = (int32_t *)ctx->mlws.p;                 // first 256 bytes: the frame hand-out counter
+        ma.wsA = (uint8_t *)ctx->mlws.p + 256;
         ma.wsR = ma.wsA + perA * grid;
+        LDPC_HIP_TRY(ctx, hipMemsetAsync(ma.work, 0, sizeof(int32_t), ctx->stream));
+        int ml_threads = 1024;
+        if (const char *e = getenv("LDPC_AMD_ML_THREADS")) {
+            const int v = atoi(e);
+            if (v == 256 || v == 512 || v == 1024) ml_threads = v;
+        }
         auto kfn = ldpc_ml_kernel;
         LDPC_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, total));
         hipEvent_t ev = prof_begin(ctx);
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(1024), (size_t)total, ctx->stream, ma);
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(ml_threads), (size_t)total, ctx->stream, ma);
         LDPC_HIP_TRY(ctx, hipGetLastError());
         prof_end(ctx, LDPC_AMD_PROF_ML, ev);
     }
@@ -1396,6 +1418,28 @@ int launch_selftest(ldpc_amd_ctx *ctx)
     LDPC_HIP_TRY(ctx, hipMemcpyAsync(&bad, d, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (bad != 0) return set_error(ctx, LDPC_AMD_EHIP, "GF(256) self-test: %d mismatches", bad);
+    return LDPC_AMD_OK;
+}
+
+int launch_copy_probe(ldpc_amd_ctx *ctx, const uint8_t *src, uint8_t *dst, uint64_t bytes, int reps, double *ms)
+{
+    hipEvent_t e0, e1;
+    LDPC_HIP_TRY(ctx, hipEventCreate(&e0));
+    LDPC_HIP_TRY(ctx, hipEventCreate(&e1));
+    const uint64_t chunks = bytes / 16;
+    const int grid = (int)std::min<uint64_t>((chunks + 1023) / 1024, 256 * 16);
+    hipLaunchKernelGGL(copy_probe_kernel, dim3(grid), dim3(1024), 0, ctx->stream, src, dst, chunks);  // warm-up
+    LDPC_HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < reps; i++)
+        hipLaunchKernelGGL(copy_probe_kernel, dim3(grid), dim3(1024), 0, ctx->stream, src, dst, chunks);
+    LDPC_HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    LDPC_HIP_TRY(ctx, hipGetLastError());
+    LDPC_HIP_TRY(ctx, hipEventSynchronize(e1));
+    float t = 0.f;
+    LDPC_HIP_TRY(ctx, hipEventElapsedTime(&t, e0, e1));
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *ms = (double)t / reps;
     return LDPC_AMD_OK;
 }
 
