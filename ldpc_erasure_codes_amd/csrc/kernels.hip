@@ -1358,6 +1358,24 @@ int launch_rs_decode(ldpc_amd_ctx *ctx, const HostRs &rs, int S, int64_t nblocks
     a.lds_ex = off; off += 512;
     a.lds_misc = off; off += 16;
     if (off > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "RS decode: LDS need %d bytes", off);
+    const char *rs_env = getenv("LDPC_AMD_RS");
+    if (S == 1 && R <= 32 && rs.k <= 256 && !(rs_env && strcmp(rs_env, "generic") == 0)) {
+        // one wavefront per block, system in registers
+        RsFastLds L{};
+        int o = 0;
+        L.lgp = o; o += align_up(R * rs.k, 16);
+        L.lg16 = o; o += 512;
+        L.ex = o; o += 1024;
+        L.mtl = o; o += 8192;
+        L.wave0 = o; L.wstride = 1024 + 64;
+        const int nw = 4;
+        o += nw * L.wstride;
+        const int wgs = std::max(1, std::min(8, kLdsMax / o));
+        const int grid = (int)std::min<int64_t>((nblocks + nw - 1) / nw, (int64_t)ctx->sm_count * wgs);
+        hipLaunchKernelGGL(rs_decode_s1_kernel, dim3(grid), dim3(64 * nw), (size_t)o, ctx->stream, a, L);
+        LDPC_HIP_TRY(ctx, hipGetLastError());
+        return LDPC_AMD_OK;
+    }
     const int threads = (S == 1) ? 64 : 256;
     int grid = (int)std::min<int64_t>(nblocks, (int64_t)ctx->sm_count * (S == 1 ? 16 : 4));
     if (S != 1) {
