@@ -214,6 +214,7 @@ static int register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_pt
     // neighbours are known.  Only valid when the code is in triangle form; otherwise encode is refused.
     std::vector<uint32_t> enc_steps;
     std::vector<uint16_t> enc_lvlend;
+    std::vector<uint8_t> enc_invc(1, 1);
     int enc_nlevels = 0;
     {
         bool triangle = true;
@@ -236,6 +237,11 @@ static int register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_pt
             for (int r = 0; r < m; r++) enc_steps[fill[lvl[r]]++] = (uint32_t)r | ((uint32_t)(k + r) << 16);
             enc_lvlend[0] = 0;
             for (int L = 1; L <= enc_nlevels; L++) enc_lvlend[L] = (uint16_t)start[L + 1];
+            enc_invc.assign(m, 1);
+            for (int s_ = 0; s_ < m; s_++) {
+                const int r = (int)(enc_steps[s_] & 0xFFFFu);
+                enc_invc[s_] = gf.inv[hc->coefs[row_ptr[r + 1] - 1]];   // the diagonal entry is the row's last
+            }
         } else {
             enc_nlevels = 0;
             enc_steps.assign(1, 0);
@@ -277,7 +283,7 @@ static int register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_pt
     if ((rc = upload(ctx, hc, hc->row_ptr, &d.row_ptr)) || (rc = upload(ctx, hc, edges, &d.edges)) ||
         (rc = upload(ctx, hc, ell_col, &d.ell_col)) || (rc = upload(ctx, hc, ell_logc, &d.ell_logc)) ||
         (rc = upload(ctx, hc, ell_coef, &d.ell_coef)) || (rc = upload(ctx, hc, cell, &d.cell)) ||
-        (rc = upload(ctx, hc, enc_src, &d.enc_src)) ||
+        (rc = upload(ctx, hc, enc_src, &d.enc_src)) || (rc = upload(ctx, hc, enc_invc, &d.enc_invc)) ||
         (rc = upload(ctx, hc, enc_steps, &d.enc_steps)) || (rc = upload(ctx, hc, enc_lvlend, &d.enc_lvlend))) {
         free_code(hc);
         return rc;

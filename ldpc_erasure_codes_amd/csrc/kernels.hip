@@ -205,6 +205,7 @@ struct PeelArgs {
     uint32_t *sched_hdr;    // [nframes][2]  nsteps, maxlvl
     uint32_t *sched_steps;  // [nframes][m]
     uint16_t *sched_lvlend; // [nframes][m+1]
+    uint8_t *sched_invc;    // [nframes][m]  inverse of the coefficient step i divides by (packet kernel)
     int32_t *big_list;      // [0] = count, [1..] frames with more than tcap steps (scatter tier 2), or nullptr
     int tcap;
     // ML hand-off
@@ -352,7 +353,18 @@ __global__ __launch_bounds__(1024) void ldpc_peel_kernel(PeelArgs a)
             if (a.big_list && nsteps > a.tcap) a.big_list[1 + atomicAdd(&a.big_list[0], 1)] = (int32_t)f;
         }
         uint32_t *gs = a.sched_steps + f * m;
-        for (int i = lane; i < nsteps; i += kWave) gs[i] = sorted[i];
+        uint8_t *gi = a.sched_invc + f * m;
+        for (int i = lane; i < nsteps; i += kWave) {
+            const uint32_t step = sorted[i];
+            gs[i] = step;
+            // the coefficient of the solved symbol in its check (:47 divides by it): found once here, not by every
+            // slice workgroup of the packet kernel
+            const uint32_t row = step & 0xFFFFu, t = step >> 16;
+            int pos = 0;
+#pragma unroll
+            for (int tt = 0; tt < MAXDEG; tt++) pos = (ell_col[tt * mpad + row] == t) ? tt : pos;
+            gi[i] = c_inv[cd.ell_coef[(size_t)pos * mpad + row]];
+        }
         uint16_t *gl = a.sched_lvlend + f * (m + 1);
         for (int i = lane; i <= maxlvl; i += kWave) gl[i] = (uint16_t)lvlend[i];
         LDPC_STAMP(4);  // schedule write-out
@@ -559,6 +571,7 @@ struct ScatterArgs {
     const uint32_t *sched_hdr;
     const uint32_t *sched_steps;
     const uint16_t *sched_lvlend;
+    const uint8_t *sched_invc;
     int in_rows;              // rows per input frame: n (decode) or k (encode: rows >= k are the unknowns)
     int static_sched;         // encode: the code's static schedule / lists are used for every frame
     int inplace;              // out == sym: received rows stay where they are, only erased rows are written
@@ -629,44 +642,62 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     uint16_t *tgt = reinterpret_cast<uint16_t *>(smem + a.lds_tgt);
     uint8_t *invc = smem + a.lds_invc;
     uint16_t *lvlend = reinterpret_cast<uint16_t *>(smem + a.lds_lvlend);
-    uint32_t *solved = reinterpret_cast<uint32_t *>(smem + a.lds_solved);
     uint32_t *mt = reinterpret_cast<uint32_t *>(smem + a.lds_mt);
     uint8_t *rk = smem + a.lds_soc;  // row kinds, [n]
     uint16_t *soc = reinterpret_cast<uint16_t *>(smem + a.lds_chk);  // check -> slot of the step that uses it, 0xFFFF
 
+    LDPC_STAMP_INIT;
     const int nsteps = a.static_sched ? cd.m : (int)a.sched_hdr[2 * f];
     const int nlev = a.static_sched ? cd.enc_nlevels : (int)a.sched_hdr[2 * f + 1];
     const uint32_t *gs = a.static_sched ? cd.enc_steps : a.sched_steps + f * cd.m;
     const uint16_t *gle = a.static_sched ? cd.enc_lvlend : a.sched_lvlend + f * (cd.m + 1);
-    for (int i = tid; i < (n + 31) / 32; i += nthr) solved[i] = 0;
-    for (int i = tid; i < (cd.m + 1) / 2; i += nthr) reinterpret_cast<uint32_t *>(soc)[i] = 0xFFFFFFFFu;
+    const uint8_t *gic = a.static_sched ? cd.enc_invc : a.sched_invc + f * cd.m;
+    const uint8_t *erf = a.erased ? a.erased + f * (int64_t)n : nullptr;
+    // Set-up costs one global-memory latency: everything that comes from global memory (this thread's steps, erasure
+    // flags, level offsets, multiply tables) is requested first, the LDS is initialised while the loads are in flight.
+    constexpr int SPT = 2, EPT = 4;             // steps / symbols per thread held in registers (m <= 2048, n <= 4096)
+    uint32_t stp[SPT];
+    uint32_t siv[SPT], erv[EPT];
+#pragma unroll
+    for (int u = 0; u < SPT; u++) {
+        const int s = tid + u * nthr;
+        stp[u] = s < nsteps ? gs[s] : 0u;
+        siv[u] = s < nsteps ? (uint32_t)gic[s] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < EPT; u++) {
+        const int j = tid + u * nthr;
+        erv[u] = (j < n) ? (erf ? (uint32_t)erf[j] : (j >= a.in_rows ? 1u : 0u)) : 0u;
+    }
     for (int i = tid; i < 2048; i += nthr) mt[i] = c_mul3[i];
     for (int i = tid; i <= nlev; i += nthr) lvlend[i] = gle[i];
+    for (int i = tid; i < (cd.m + 1) / 2; i += nthr) reinterpret_cast<uint32_t *>(soc)[i] = 0xFFFFFFFFu;
     for (int i = tid; i < nsteps * LPR; i += nthr) reinterpret_cast<U4 *>(acc)[i] = U4{0, 0, 0, 0};
+    // row kinds: 1 received, 2 erased and never solved (written as 0), 0 erased and solved in phase B (set below)
+#pragma unroll
+    for (int u = 0; u < EPT; u++) {
+        const int j = tid + u * nthr;
+        if (j < n) rk[j] = erv[u] ? (uint8_t)2 : (uint8_t)1;
+    }
+    for (int j = tid + EPT * nthr; j < n; j += nthr)
+        rk[j] = (erf ? (erf[j] != 0) : (j >= a.in_rows)) ? (uint8_t)2 : (uint8_t)1;
     __syncthreads();
-    for (int s = tid; s < nsteps; s += nthr) {
-        const uint32_t step = gs[s];
+    auto put_step = [&](int s, uint32_t step, uint32_t iv) {
         const uint32_t row = step & 0xFFFFu, t = step >> 16;
         tgt[s] = (uint16_t)t;
         soc[row] = (uint16_t)s;
-        uint32_t ct = 1;
-        for (uint32_t e = cd.row_ptr[row]; e < cd.row_ptr[row + 1]; e++) {
-            const uint32_t ed = cd.edges[e];
-            if ((ed & 0xFFFFu) == t) ct = (ed >> 16) & 0xFFu;
-        }
-        invc[s] = c_inv[ct];
-        atomicOr(&solved[t >> 5], 1u << (t & 31));
+        invc[s] = (uint8_t)iv;
+        rk[t] = 0;
+    };
+#pragma unroll
+    for (int u = 0; u < SPT; u++) {
+        const int s = tid + u * nthr;
+        if (s < nsteps) put_step(s, stp[u], siv[u]);
     }
-    __syncthreads();
-    {   // row kinds: 1 received, 2 erased and never solved (written as 0), 0 erased and solved in phase B
-        const uint8_t *erf = a.erased ? a.erased + f * (int64_t)n : nullptr;
-        for (int j = tid; j < n; j += nthr) {
-            const bool e = erf ? (erf[j] != 0) : (j >= a.in_rows);
-            rk[j] = e ? (((solved[j >> 5] >> (j & 31)) & 1u) ? (uint8_t)0 : (uint8_t)2) : (uint8_t)1;
-        }
-    }
+    for (int s = tid + SPT * nthr; s < nsteps; s += nthr) put_step(s, gs[s], gic[s]);
     __syncthreads();
 
+    LDPC_STAMP(12);  // scatter: set-up
     const uint8_t *fin = a.sym + f * (int64_t)a.in_rows * S + (int64_t)sl * B + gl * 16;
     uint8_t *fout = a.out + f * (int64_t)n * S + (int64_t)sl * B + gl * 16;
     // H's static column lists (check | coef << 16); the encoder's are already in (slot | coef << 16) form
@@ -751,33 +782,51 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
             cur = nxt;
         }
     }
+    LDPC_STAMP(13);  // scatter: streaming phase
     __syncthreads();
+    LDPC_STAMP(14);  // scatter: wait for the slowest wave of the stream
 
-    // ---- phase B: finalise the solved symbols level by level and scatter them on
+    // ---- phase B: finalise the solved symbols level by level and scatter them on.  A wave's first step of the next
+    //      level is known in advance, so its column list is requested before the barrier instead of after it.
+    auto load_list = [&](int s, int s1, uint32_t (&ew)[KQ]) {
+#pragma unroll
+        for (int q = 0; q < KQ; q++) ew[q] = 0xFFFFFFFFu;
+        if (s < s1) {
+            const int t = tgt[s];
+#pragma unroll
+            for (int q = 0; q < KQ; q++) {
+                const int idx = gl + q * LPR;
+                if (idx < cdw) ew[q] = spad[((int64_t)t << cd.cdw_shift) + idx];
+            }
+        }
+    };
+    uint32_t ewn[KQ];
+    load_list((nlev >= 1 ? (int)lvlend[0] : 0) + wave * RPW + g, nlev >= 1 ? (int)lvlend[1] : 0, ewn);
     for (int L = 1; L <= nlev; L++) {
         const int s0 = lvlend[L - 1], s1 = lvlend[L];
         for (int sb = s0 + wave * RPW; sb < s1; sb += nw * RPW) {
             const int s = sb + g;
             U4 val = {0, 0, 0, 0};
             uint32_t ew[KQ];
+            if (sb == s0 + wave * RPW) {
 #pragma unroll
-            for (int q = 0; q < KQ; q++) ew[q] = 0xFFFFFFFFu;
+                for (int q = 0; q < KQ; q++) ew[q] = ewn[q];
+            } else {
+                load_list(s, s1, ew);
+            }
             if (s < s1) {
                 const int t = tgt[s];
                 const U4 a16 = *reinterpret_cast<const U4 *>(acc + (size_t)s * B + gl * 16);
                 val = gfmul16(lds_multab(mt, invc[s]), a16);
                 stream_store16<NT>(fout + (int64_t)t * S, val);
-#pragma unroll
-                for (int q = 0; q < KQ; q++) {
-                    const int idx = gl + q * LPR;
-                    if (idx < cdw) ew[q] = spad[((int64_t)t << cd.cdw_shift) + idx];
-                }
             }
             to_slots(ew, (s < s1) ? (uint32_t)s : 0xFFFFu);
             scatter(val, ew);
         }
+        if (L < nlev) load_list((int)lvlend[L] + wave * RPW + g, (int)lvlend[L + 1], ewn);
         __syncthreads();
     }
+    LDPC_STAMP(15);  // scatter: level phase
 }
 
 // Tier 1: one workgroup per (frame, slice); frames with more than tcap steps are left to tier 2.
@@ -786,9 +835,10 @@ template <int LPR, int R, bool NT, int WPE, bool INPLACE>
 __global__ __launch_bounds__(1024, WPE) void ldpc_scatter_kernel(ScatterArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // Optional XCD-aware placement (LDPC_AMD_SCATTER_XCD=1): workgroups are dealt round-robin over the 8 XCDs, so
-    // block b = 8 i + x handling slice i % nslices of frame (i / nslices) * 8 + x keeps the slices of a frame (which
-    // read the same per-frame lists) on one L2.  Speed only; measured neutral, so off by default.
+    // XCD-aware placement (LDPC_AMD_SCATTER_XCD=0 switches it off): workgroups are dealt round-robin over the 8 XCDs, so
+    // block b = 8 i + x handling slice i % nslices of frame (i / nslices) * 8 + x keeps the slices of a frame -- the
+    // four 256-byte pieces of every 1 KB row, and the frame's schedule -- on one XCD at about the same time.
+    // Speed only (3 % on the 4096-frame batch).
     int64_t f;
     int sl;
     if (a.xcd_map && (a.nframes & 7) == 0) {
@@ -1097,7 +1147,7 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
     const char *env_nt = getenv("LDPC_AMD_SCATTER_NT");
     const bool nt = env_nt ? atoi(env_nt) != 0 : true;
     const char *env_x = getenv("LDPC_AMD_SCATTER_XCD");
-    sa.xcd_map = env_x ? atoi(env_x) : 0;  // measured: no gain (3.25 vs 3.23 ms), kept as a knob
+    sa.xcd_map = env_x ? atoi(env_x) : 1;  // measured: 3.12 vs 3.22 ms once the set-up was shortened; =0 switches it off
     const dim3 grid((unsigned)(sa.nframes * sa.nslices));
     // tier 1
     sa.tcap = p.tcap; sa.big_list = nullptr;
@@ -1228,11 +1278,12 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         LDPC_HIP_TRY(ctx, launch_peel_t<true>(pa, wpb, ctx->stream));
         prof_end(ctx, LDPC_AMD_PROF_PEEL, ev);
     } else {
-        const size_t hdr = (size_t)nf * 2 * 4, st = (size_t)nf * cd.m * 4, le = (size_t)nf * (cd.m + 1) * 2;
-        const size_t o1 = (hdr + 255) & ~(size_t)255, o2 = (o1 + st + 255) & ~(size_t)255;
-        if ((rc = scratch_reserve(ctx, ctx->sched, o2 + le))) return rc;
+        const size_t hdr = (size_t)nf * 2 * 4, st = (size_t)nf * cd.m * 4, le = (size_t)nf * (cd.m + 1) * 2, iv = (size_t)nf * cd.m;
+        const size_t o1 = (hdr + 255) & ~(size_t)255, o2 = (o1 + st + 255) & ~(size_t)255, o3 = (o2 + le + 255) & ~(size_t)255;
+        if ((rc = scratch_reserve(ctx, ctx->sched, o3 + iv))) return rc;
         unsigned char *base = (unsigned char *)ctx->sched.p;
         pa.sched_hdr = (uint32_t *)base; pa.sched_steps = (uint32_t *)(base + o1); pa.sched_lvlend = (uint16_t *)(base + o2);
+        pa.sched_invc = base + o3;
         if (use_scatter) {
             pa.tcap = plan.tcap;
             pa.big_list = plan.two_tier ? (int32_t *)ctx->biglist.p : nullptr;
@@ -1246,6 +1297,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             sa.code = cd; sa.S = d.S; sa.nslices = plan.nslices; sa.nframes = nf; sa.sym = d.sym; sa.erased = d.erased; sa.out = d.out;
             sa.in_rows = cd.n; sa.static_sched = 0; sa.inplace = d.inplace;
             sa.sched_hdr = pa.sched_hdr; sa.sched_steps = pa.sched_steps; sa.sched_lvlend = pa.sched_lvlend;
+            sa.sched_invc = pa.sched_invc;
             ev = prof_begin(ctx);
             if ((rc = launch_scatter(ctx, plan, sa, (const int32_t *)ctx->biglist.p))) return rc;
             prof_end(ctx, LDPC_AMD_PROF_APPLY, ev);
@@ -1445,7 +1497,7 @@ int launch_copy_probe(ldpc_amd_ctx *ctx, const uint8_t *src, uint8_t *dst, uint6
     LDPC_HIP_TRY(ctx, hipEventCreate(&e0));
     LDPC_HIP_TRY(ctx, hipEventCreate(&e1));
     const uint64_t chunks = bytes / 16;
-    const int grid = (int)std::min<uint64_t>((chunks + 1023) / 1024, 256 * 16);
+    const int grid = (int)std::min<uint64_t>((chunks + 1023) / 1024, 16384);
     hipLaunchKernelGGL(copy_probe_kernel, dim3(grid), dim3(1024), 0, ctx->stream, src, dst, chunks);  // warm-up
     LDPC_HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
     for (int i = 0; i < reps; i++)

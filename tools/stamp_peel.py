@@ -29,7 +29,7 @@ def main():
     n, k, _ = ctx.code_info(h)
     F = 4096
     dev = torch.device("cuda", 0)
-    for S in (1, 64):
+    for S in (1, 64, 1024):
         src_t = torch.empty((F, k, S), dtype=torch.uint8, device=dev)
         ctx.synth_source(1, 0, F, k, S, src_t)
         cw = ctx.encode(h, src_t if S > 1 else src_t.reshape(F, k))
@@ -46,6 +46,11 @@ def main():
         for i, name in enumerate(PHASES):
             if buf[i]:
                 print(f"   {name:24s} {buf[i] / (reps * F):9.0f} cycles  {100.0 * buf[i] / tot:5.1f} %")
+        stot = sum(buf[i] for i in range(12, 16))
+        if stot:
+            print(f"   packet kernel (per wavefront sums): {stot / (reps * F):.0f} ticks per frame")
+            for i, name in zip(range(12, 16), ["set-up", "streaming phase", "wait after stream", "level phase"]):
+                print(f"      {name:22s} {100.0 * buf[i] / stot:5.1f} %")
     ctx.close()
 
 
