@@ -21,6 +21,7 @@
 //   * Residual frames are compacted into a list and solved by the ML kernel (exact pivot order of the
 //     reference, including its behaviour on rank-deficient systems).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -577,6 +578,7 @@ struct ScatterArgs {
     int inplace;              // out == sym: received rows stay where they are, only erased rows are written
     int xcd_map;              // place the slices of a frame on one XCD
     int tcap;                 // tier 1 handles frames with at most tcap steps (its LDS holds tcap accumulators)
+    int nslots;               // accumulator slots in this launch's LDS (tcap in tier 1, m in tier 2 / encode)
     const int32_t *big_list;  // tier 2: [0] = count, [1..] ids of the frames with more steps; nullptr in tier 1
     int lds_acc, lds_tgt, lds_invc, lds_lvlend, lds_solved, lds_mt, lds_soc, lds_chk;
 };
@@ -669,6 +671,24 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         const int j = tid + u * nthr;
         erv[u] = (j < n) ? (erf ? (uint32_t)erf[j] : (j >= a.in_rows ? 1u : 0u)) : 0u;
     }
+    // The column lists of the symbols solved in phase B go to the LDS left over behind the accumulators of this
+    // frame (nsteps of nslots used), so that phase B issues no global load: a load behind the phase's row stores
+    // would wait for those stores (one memory counter), once per level.  Frames without room keep the global lists.
+    const bool lds_lists = !a.static_sched && (int64_t)nsteps * (B + 4 * cdw) <= (int64_t)a.nslots * B;
+    uint32_t *slist = reinterpret_cast<uint32_t *>(acc + (size_t)nsteps * B);   // [nsteps][cdw]
+    constexpr int LPT = 2;                      // list words per thread held in registers
+    uint32_t lw[LPT];
+    if (lds_lists) {
+#pragma unroll
+        for (int u = 0; u < LPT; u++) {
+            const int e = tid + u * nthr;
+            lw[u] = 0xFFFFFFFFu;
+            if (e < nsteps * cdw) {
+                const int s = e / cdw, idx = e - s * cdw;
+                lw[u] = cd.cell[((int64_t)(gs[s] >> 16) << cd.cdw_shift) + idx];
+            }
+        }
+    }
     for (int i = tid; i < 2048; i += nthr) mt[i] = c_mul3[i];
     for (int i = tid; i <= nlev; i += nthr) lvlend[i] = gle[i];
     for (int i = tid; i < (cd.m + 1) / 2; i += nthr) reinterpret_cast<uint32_t *>(soc)[i] = 0xFFFFFFFFu;
@@ -695,6 +715,17 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         if (s < nsteps) put_step(s, stp[u], siv[u]);
     }
     for (int s = tid + SPT * nthr; s < nsteps; s += nthr) put_step(s, gs[s], gic[s]);
+    if (lds_lists) {
+#pragma unroll
+        for (int u = 0; u < LPT; u++) {
+            const int e = tid + u * nthr;
+            if (e < nsteps * cdw) slist[e] = lw[u];
+        }
+        for (int e = tid + LPT * nthr; e < nsteps * cdw; e += nthr) {
+            const int s = e / cdw, idx = e - s * cdw;
+            slist[e] = cd.cell[((int64_t)(gs[s] >> 16) << cd.cdw_shift) + idx];
+        }
+    }
     __syncthreads();
 
     LDPC_STAMP(12);  // scatter: set-up
@@ -786,46 +817,53 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     __syncthreads();
     LDPC_STAMP(14);  // scatter: wait for the slowest wave of the stream
 
-    // ---- phase B: finalise the solved symbols level by level and scatter them on.  A wave's first step of the next
-    //      level is known in advance, so its column list is requested before the barrier instead of after it.
-    auto load_list = [&](int s, int s1, uint32_t (&ew)[KQ]) {
+    // ---- phase B: finalise the solved symbols level by level and scatter them on.  Two instantiations: with the
+    //      lists in LDS the loop contains no global load, so nothing in it waits on the memory counter (a load would
+    //      wait for the row stores issued before it, once per level); the other one reads the lists from global memory
+    //      and requests a wave's first list of the next level before the barrier.
+    auto phase_b = [&](auto lds_tag) {
+        constexpr bool LL = decltype(lds_tag)::value;
+        auto load_list = [&](int s, int s1, uint32_t (&ew)[KQ]) {
 #pragma unroll
-        for (int q = 0; q < KQ; q++) ew[q] = 0xFFFFFFFFu;
-        if (s < s1) {
-            const int t = tgt[s];
-#pragma unroll
-            for (int q = 0; q < KQ; q++) {
-                const int idx = gl + q * LPR;
-                if (idx < cdw) ew[q] = spad[((int64_t)t << cd.cdw_shift) + idx];
-            }
-        }
-    };
-    uint32_t ewn[KQ];
-    load_list((nlev >= 1 ? (int)lvlend[0] : 0) + wave * RPW + g, nlev >= 1 ? (int)lvlend[1] : 0, ewn);
-    for (int L = 1; L <= nlev; L++) {
-        const int s0 = lvlend[L - 1], s1 = lvlend[L];
-        for (int sb = s0 + wave * RPW; sb < s1; sb += nw * RPW) {
-            const int s = sb + g;
-            U4 val = {0, 0, 0, 0};
-            uint32_t ew[KQ];
-            if (sb == s0 + wave * RPW) {
-#pragma unroll
-                for (int q = 0; q < KQ; q++) ew[q] = ewn[q];
-            } else {
-                load_list(s, s1, ew);
-            }
+            for (int q = 0; q < KQ; q++) ew[q] = 0xFFFFFFFFu;
             if (s < s1) {
                 const int t = tgt[s];
-                const U4 a16 = *reinterpret_cast<const U4 *>(acc + (size_t)s * B + gl * 16);
-                val = gfmul16(lds_multab(mt, invc[s]), a16);
-                stream_store16<NT>(fout + (int64_t)t * S, val);
+#pragma unroll
+                for (int q = 0; q < KQ; q++) {
+                    const int idx = gl + q * LPR;
+                    if (idx < cdw) ew[q] = LL ? slist[s * cdw + idx] : spad[((int64_t)t << cd.cdw_shift) + idx];
+                }
             }
-            to_slots(ew, (s < s1) ? (uint32_t)s : 0xFFFFu);
-            scatter(val, ew);
+        };
+        uint32_t ewn[KQ];
+        if (!LL) load_list((nlev >= 1 ? (int)lvlend[0] : 0) + wave * RPW + g, nlev >= 1 ? (int)lvlend[1] : 0, ewn);
+        for (int L = 1; L <= nlev; L++) {
+            const int s0 = lvlend[L - 1], s1 = lvlend[L];
+            for (int sb = s0 + wave * RPW; sb < s1; sb += nw * RPW) {
+                const int s = sb + g;
+                U4 val = {0, 0, 0, 0};
+                uint32_t ew[KQ];
+                if (!LL && sb == s0 + wave * RPW) {
+#pragma unroll
+                    for (int q = 0; q < KQ; q++) ew[q] = ewn[q];
+                } else {
+                    load_list(s, s1, ew);
+                }
+                if (s < s1) {
+                    const int t = tgt[s];
+                    const U4 a16 = *reinterpret_cast<const U4 *>(acc + (size_t)s * B + gl * 16);
+                    val = gfmul16(lds_multab(mt, invc[s]), a16);
+                    stream_store16<NT>(fout + (int64_t)t * S, val);
+                }
+                to_slots(ew, (s < s1) ? (uint32_t)s : 0xFFFFu);
+                scatter(val, ew);
+            }
+            if (!LL && L < nlev) load_list((int)lvlend[L] + wave * RPW + g, (int)lvlend[L + 1], ewn);
+            __syncthreads();
         }
-        if (L < nlev) load_list((int)lvlend[L] + wave * RPW + g, (int)lvlend[L + 1], ewn);
-        __syncthreads();
-    }
+    };
+    if (lds_lists) phase_b(std::true_type{});
+    else phase_b(std::false_type{});
     LDPC_STAMP(15);  // scatter: level phase
 }
 
@@ -1150,7 +1188,7 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
     sa.xcd_map = env_x ? atoi(env_x) : 1;  // measured: 3.12 vs 3.22 ms once the set-up was shortened; =0 switches it off
     const dim3 grid((unsigned)(sa.nframes * sa.nslices));
     // tier 1
-    sa.tcap = p.tcap; sa.big_list = nullptr;
+    sa.tcap = p.tcap; sa.nslots = p.tcap; sa.big_list = nullptr;
     scatter_set_lds(sa, p, p.tcap);
 #define LDPC_SCATTER_T1(NTV, WPE, IPV)                                                                         \
     {                                                                                                        \
@@ -1170,7 +1208,7 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
 #undef LDPC_SCATTER_T1
     LDPC_HIP_TRY(ctx, hipGetLastError());
     if (p.two_tier) {
-        sa.tcap = sa.code.m; sa.big_list = big_list;
+        sa.tcap = sa.code.m; sa.nslots = sa.code.m; sa.big_list = big_list;
         scatter_set_lds(sa, p, sa.code.m);
         const dim3 g2((unsigned)std::min<int64_t>(sa.nframes * sa.nslices, ctx->sm_count));
 #define LDPC_SCATTER_T2(NTV, IPV)                                                                            \

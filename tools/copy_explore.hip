@@ -38,11 +38,16 @@ __global__ __launch_bounds__(1024) void copy_gs(const U4 *src, U4 *dst, uint64_t
 
 // the packet kernel's pattern: workgroup = (frame, slice); it walks the rows of a frame touching `piece` bytes of each
 // `rowbytes`-byte row (lanes_per_row lanes x 16 B), U row batches in flight
-template <bool NT, int U>
+template <bool NT, int U, bool XCD = false>
 __global__ __launch_bounds__(1024) void copy_sliced(const uint8_t *src, uint8_t *dst, int rows, int rowbytes, int piece, int nslices)
 {
-    const int64_t f = blockIdx.x / nslices;
-    const int sl = blockIdx.x % nslices;
+    int64_t f = blockIdx.x / nslices;
+    int sl = blockIdx.x % nslices;
+    if (XCD) {   // workgroups are dealt round-robin over the 8 XCDs: keep the slices of a frame on one XCD
+        const int64_t x = blockIdx.x & 7, i = blockIdx.x >> 3;
+        f = (i / nslices) * 8 + x;
+        sl = (int)(i % nslices);
+    }
     const int lpr = piece / 16;
     const int rpb = blockDim.x / lpr;          // rows per pass of the workgroup
     const int r0 = threadIdx.x / lpr, gl = threadIdx.x % lpr;
@@ -137,5 +142,17 @@ int main()
         snprintf(nm, sizeof nm, "copy sliced NT piece=%4d U=4", piece);
         rep(nm, timeit([&] { copy_sliced<true, 4><<<(int)(frames * ns), 1024>>>(a, b, rows, rowbytes, piece, ns); }), rw);
     }
+    for (int piece : {512, 256}) {
+        char nm[128];
+        const int ns = rowbytes / piece;
+        snprintf(nm, sizeof nm, "copy sliced NT piece=%4d U=1 XCD-mapped", piece);
+        rep(nm, timeit([&] { copy_sliced<true, 1, true><<<(int)(frames * ns), 1024>>>(a, b, rows, rowbytes, piece, ns); }), rw);
+        snprintf(nm, sizeof nm, "copy sliced NT piece=%4d U=2 XCD-mapped", piece);
+        rep(nm, timeit([&] { copy_sliced<true, 2, true><<<(int)(frames * ns), 1024>>>(a, b, rows, rowbytes, piece, ns); }), rw);
+    }
+    rep("copy grid-stride NT  U=1 grid=16384 (again, clocks warm)", timeit([&] { copy_gs<true, true, 1><<<16384, 1024>>>((const U4 *)a, (U4 *)b, chunks); }), rw);
+    rep("copy sliced NT piece= 256 U=1 (again)", timeit([&] { copy_sliced<true, 1><<<(int)(frames * 4), 1024>>>(a, b, rows, rowbytes, 256, 4); }), rw);
+    rep("read-only  NT U=1 grid=4096 (again)", timeit([&] { read_gs<true, 1><<<4096, 1024>>>((const U4 *)a, sink, chunks); }), ro);
+    rep("write-only plain grid=4096 (again)", timeit([&] { fill_gs<false><<<4096, 1024>>>((U4 *)b, chunks); }), ro);
     return 0;
 }
