@@ -110,6 +110,27 @@ def cpu_baseline(S, cores, frames_per_core):
             "per_core": rate / cores}
 
 
+def cpu_cfg1(reps=200):
+    """BASELINE configs[0] (the reference's own CPU-runnable case): ONE binary (2040,1530) frame, message passing only
+    (Matlab/My_LDPC_Erasure_Decoder.m, 50 sweeps max), FPGA data_in erasures at PER 9/64 -- the oracle on one core."""
+    from ldpc_erasure_codes_amd import codes, synth
+    from oracle import oracle_py
+    code = codes.load_builtin(CODE_IND, 0)  # coefficient seed 0 = the binary code (all ones)
+    oc = oracle_py.OracleCode(code)
+    era = synth.fpga_erasures(1, 9, reps, code.n)
+    busy, ok, sweeps = 0.0, 0, 0
+    for f in range(reps):
+        recv = np.zeros(code.n, dtype=np.int16)  # the all-zero codeword, as the FPGA source sends (data_in)
+        recv[era[f] != 0] = -1
+        t0 = time.perf_counter()
+        msg, it = oc.binary_mp(recv, itenum=50)
+        busy += time.perf_counter() - t0
+        ok += int(not (msg < 0).any())
+        sweeps += it
+    return {"workload": "BASELINE cfg1: 1 binary (2040,1530) frame, MP only (<= 50 sweeps), PER 9/64, oracle on 1 core",
+            "us_per_frame": busy / reps * 1e6, "frames": reps, "decoded": ok, "mean_sweeps": sweeps / reps}
+
+
 # ----------------------------------------------------------------------------------------------------
 def run_gpu(args, rank, world, local_rank):
     import torch
@@ -265,6 +286,7 @@ def main():
         cpu[args.S] = cpu_baseline(args.S, cores, args.cpu_frames or (1024 if args.S > 1 else 65536))
         if args.S != 1:
             cpu[1] = cpu_baseline(1, cores, args.cpu_frames or 65536)
+        cpu["cfg1"] = cpu_cfg1()
 
     result, n, k = run_gpu(args, rank, world, local_rank)
     if rank != 0:
@@ -309,6 +331,8 @@ def main():
     if args.S in cpu:
         line["cpu_baseline"] = cpu[args.S]
         line["gpu_over_cpu"] = main_r["value"] / cpu[args.S]["value"]
+    if "cfg1" in cpu:
+        line["cfg1_cpu_reference_row"] = cpu["cfg1"]
     if 1 in result and args.S != 1:
         s1 = result[1]
         line["s1"] = {"note": "same batch with S=1 (one GF(256) element per symbol: the Matlab model, bit-exact incl. iterations); "

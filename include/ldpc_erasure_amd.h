@@ -160,6 +160,17 @@ int ldpc_amd_data_in(ldpc_amd_ctx *ctx, const ldpc_amd_symbol_type *data_in, uns
 /* ldpc_erasure_decoder(short num_iter, int code_ind) (ldpc_erasure_decoder_perf_tests.cl:30): decodes the
  * frames produced by the last ldpc_amd_data_in with the binary packet-XOR message-passing decoder. */
 int ldpc_amd_ldpc_erasure_decoder(ldpc_amd_ctx *ctx, short num_iter, int code_ind);
+/* The reference holds two bodies for that kernel.  ldpc_amd_ldpc_erasure_decoder follows the one the top-level design
+ * includes (ldpc_erasure_decoder_top.cl:161 -> ldpc_erasure_decoder.cl:24-105: num_iter in-order sweeps over all
+ * checks).  This entry point follows the other one, ldpc_erasure_decoder_perf_tests.cl:30-236, whose argument list is
+ * the one the host passes (main.cpp:593-596): two copies of the frame, checks [0,m/2) swept on the first and
+ * [m/2,m) on the second, merged after every iteration, stop when num_current_correct == k -- as written, including the
+ * premature stops that rule allows (merged parity symbols are counted too, :180-201). */
+int ldpc_amd_ldpc_erasure_decoder_perf_tests(ldpc_amd_ctx *ctx, short num_iter, int code_ind);
+/* Per-frame results of the last of the two decoder calls (host pointers, either may be NULL): systematic symbols
+ * still erased (:213-220, the frame-error criterion) and iterations run.  No FPGA counterpart (the FPGA streams only
+ * the running error counters); exists so that tests can compare frame by frame. */
+int ldpc_amd_fpga_frame_stats(ldpc_amd_ctx *ctx, long numFrames, int32_t *residual_sys, int32_t *iterations);
 /* data_out(global symbol_type*, int code_ind, long numFrames) (ldpc_erasure_decoder_top.cl:124-127): collects
  * the frame-error counters (ERROR_STAT); data_out, if not NULL, receives the first k symbols of the last frame. */
 int ldpc_amd_data_out(ldpc_amd_ctx *ctx, ldpc_amd_symbol_type *data_out, int code_ind, long numFrames,

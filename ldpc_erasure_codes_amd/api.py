@@ -34,6 +34,7 @@ EXPORTS = [
     "ldpc_amd_code_csr", "ldpc_amd_decode_batch", "ldpc_amd_encode_batch", "ldpc_amd_rs_create",
     "ldpc_amd_rs_generator", "ldpc_amd_rs_encode_batch", "ldpc_amd_rs_decode_batch", "ldpc_amd_synth_source",
     "ldpc_amd_synth_erasures_uniform", "ldpc_amd_synth_erasures_bursty", "ldpc_amd_data_in", "ldpc_amd_ldpc_erasure_decoder", "ldpc_amd_data_out",
+    "ldpc_amd_ldpc_erasure_decoder_perf_tests", "ldpc_amd_fpga_frame_stats",
     "ldpc_amd_set_profiling", "ldpc_amd_get_profile", "ldpc_amd_selftest", "ldpc_amd_copy_probe", "ldpc_amd_gf_tables", "ldpc_amd_version",
 ]
 
@@ -89,6 +90,8 @@ def load_library():
     L.ldpc_amd_synth_erasures_bursty.argtypes = [vp, u64, i64, i64, i32, C.c_double, C.c_double, C.c_double, vp]
     L.ldpc_amd_data_in.argtypes = [vp, vp, C.c_ushort, i32, i32, i32, C.c_long]
     L.ldpc_amd_ldpc_erasure_decoder.argtypes = [vp, C.c_short, i32]
+    L.ldpc_amd_ldpc_erasure_decoder_perf_tests.argtypes = [vp, C.c_short, i32]
+    L.ldpc_amd_fpga_frame_stats.argtypes = [vp, C.c_long, vp, vp]
     L.ldpc_amd_data_out.argtypes = [vp, vp, i32, C.c_long, C.POINTER(ErrorType)]
     L.ldpc_amd_set_profiling.argtypes = [vp, i32]
     L.ldpc_amd_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
@@ -325,6 +328,16 @@ class Context:
 
     def ldpc_erasure_decoder(self, num_iter, code_ind):
         self._check(self._L.ldpc_amd_ldpc_erasure_decoder(self._h, num_iter, code_ind), "ldpc_erasure_decoder")
+
+    def ldpc_erasure_decoder_perf_tests(self, num_iter, code_ind):
+        self._check(self._L.ldpc_amd_ldpc_erasure_decoder_perf_tests(self._h, num_iter, code_ind), "ldpc_erasure_decoder_perf_tests")
+
+    def fpga_frame_stats(self, num_frames):
+        """(systematic erasures left, iterations) per frame of the last FPGA-style decoder call."""
+        left = np.zeros(num_frames, dtype=np.int32)
+        its = np.zeros(num_frames, dtype=np.int32)
+        self._check(self._L.ldpc_amd_fpga_frame_stats(self._h, num_frames, left.ctypes.data, its.ctypes.data), "fpga_frame_stats")
+        return left, its
 
     def data_out(self, code_ind, num_frames):
         st = ErrorType()

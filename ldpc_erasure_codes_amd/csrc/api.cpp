@@ -697,14 +697,44 @@ int ldpc_amd_ldpc_erasure_decoder(ldpc_amd_ctx *ctx, short num_iter, int code_in
     const long nf = ctx->fpga_frames;
     if (nf == 0) return LDPC_AMD_OK;
     int rc;
-    if ((rc = scratch_reserve(ctx, ctx->fpga_stats, sizeof(int32_t) * (size_t)(nf + 16)))) return rc;
+    if ((rc = scratch_reserve(ctx, ctx->fpga_stats, sizeof(int32_t) * (size_t)(2 * nf + 16)))) return rc;
     // flags-only decode: the payload is the all-zero codeword, only the erasure pattern matters
     DecodeArgs d{};
     d.code = hc->dev; d.S = 16; d.nframes = nf; d.in_rows = hc->n; d.max_sweeps = num_iter; d.do_ml = 0;
     d.erased = (const uint8_t *)ctx->fpga_erased.p;
     d.flags_only = 1;
     d.residual_sys = (int32_t *)ctx->fpga_stats.p + 16;
+    d.sweeps = (int32_t *)ctx->fpga_stats.p + 16 + nf;
     return launch_decode(ctx, d);
+}
+
+int ldpc_amd_ldpc_erasure_decoder_perf_tests(ldpc_amd_ctx *ctx, short num_iter, int code_ind)
+{
+    if (!ctx) return LDPC_AMD_EINVAL;
+    if (ctx->fpga_code_ind != code_ind) return set_error(ctx, LDPC_AMD_EINVAL, "ldpc_amd_data_in was not called for code_ind %d", code_ind);
+    int h = fpga_code(ctx, code_ind);
+    if (h < 0) return h;
+    HostCode *hc = ctx->codes[h];
+    const long nf = ctx->fpga_frames;
+    if (nf == 0) return LDPC_AMD_OK;
+    int rc;
+    if ((rc = scratch_reserve(ctx, ctx->fpga_stats, sizeof(int32_t) * (size_t)(2 * nf + 16)))) return rc;
+    LDPC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int32_t *base = (int32_t *)ctx->fpga_stats.p;
+    return launch_fpga_halves(ctx, hc->dev, nf, (const uint8_t *)ctx->fpga_erased.p, num_iter, base + 16, base + 16 + nf);
+}
+
+int ldpc_amd_fpga_frame_stats(ldpc_amd_ctx *ctx, long numFrames, int32_t *residual_sys, int32_t *iterations)
+{
+    if (!ctx) return LDPC_AMD_EINVAL;
+    if (numFrames != ctx->fpga_frames || !ctx->fpga_stats.p)
+        return set_error(ctx, LDPC_AMD_EINVAL, "fpga_frame_stats: no decoded batch of %ld frames", numFrames);
+    if (numFrames == 0) return LDPC_AMD_OK;
+    const int32_t *base = (const int32_t *)ctx->fpga_stats.p;
+    if (residual_sys) LDPC_HIP_TRY(ctx, hipMemcpyAsync(residual_sys, base + 16, sizeof(int32_t) * (size_t)numFrames, hipMemcpyDeviceToHost, ctx->stream));
+    if (iterations) LDPC_HIP_TRY(ctx, hipMemcpyAsync(iterations, base + 16 + numFrames, sizeof(int32_t) * (size_t)numFrames, hipMemcpyDeviceToHost, ctx->stream));
+    LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return LDPC_AMD_OK;
 }
 
 int ldpc_amd_data_out(ldpc_amd_ctx *ctx, ldpc_amd_symbol_type *data_out, int code_ind, long numFrames,

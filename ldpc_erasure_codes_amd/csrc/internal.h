@@ -129,6 +129,8 @@ struct DecodeArgs {
 hipError_t upload_constants(hipStream_t s);
 int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &a);
 int launch_encode(ldpc_amd_ctx *ctx, const DevCode &code, int S, int64_t nframes, const uint8_t *src, uint8_t *cw);
+int launch_fpga_halves(ldpc_amd_ctx *ctx, const DevCode &code, int64_t nframes, const uint8_t *erased, int num_iter,
+                       int32_t *residual_sys, int32_t *iterations);
 int launch_selftest(ldpc_amd_ctx *ctx);
 int launch_copy_probe(ldpc_amd_ctx *ctx, const uint8_t *src, uint8_t *dst, uint64_t bytes, int reps, double *ms);
 int launch_synth_source(ldpc_amd_ctx *ctx, uint64_t seed, int64_t frame0, int64_t nframes, int k, int S, uint8_t *d);

@@ -1501,6 +1501,30 @@ int launch_fpga_stats(ldpc_amd_ctx *ctx, const DevCode &code, int rs_n, int rs_k
     return LDPC_AMD_OK;
 }
 
+int launch_fpga_halves(ldpc_amd_ctx *ctx, const DevCode &code, int64_t nframes, const uint8_t *erased, int num_iter,
+                       int32_t *residual_sys, int32_t *iterations)
+{
+    if (nframes <= 0) return LDPC_AMD_OK;
+    const int wpb = 4;
+    const int wave0 = align_up(code.degpad * code.mpad * 2, 16);
+    const int wstride = 2 * align_up(code.n, 16);
+    const size_t lds = (size_t)wave0 + (size_t)wpb * wstride;
+    if (lds > (size_t)kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "FPGA perf decoder: LDS need %zu bytes", lds);
+    const dim3 grid((unsigned)((nframes + wpb - 1) / wpb));
+#define LDPC_FPGA_HALVES(D)                                                                                     \
+    {                                                                                                          \
+        auto kfn = fpga_halves_kernel<D>;                                                                      \
+        LDPC_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(kfn, grid, dim3(64 * wpb), lds, ctx->stream, code, nframes, erased, num_iter, residual_sys, iterations, wave0, wstride); \
+    }
+    if (code.degpad <= 8) LDPC_FPGA_HALVES(8)
+    else if (code.degpad <= 16) LDPC_FPGA_HALVES(16)
+    else LDPC_FPGA_HALVES(24)
+#undef LDPC_FPGA_HALVES
+    LDPC_HIP_TRY(ctx, hipGetLastError());
+    return LDPC_AMD_OK;
+}
+
 #ifdef LDPC_AMD_STAMPS
 extern "C" int ldpc_amd_debug_peel_stamps(ldpc_amd_ctx *ctx, unsigned long long *out16, int reset)
 {

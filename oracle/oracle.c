@@ -694,6 +694,68 @@ void oracle_threefry4x32_20(const uint32_t ctr[4], const uint32_t key[4], uint32
     ldpc_threefry4x32_20(ctr, key, out);
 }
 
+/* OpenCL/device/ldpc_erasure_decoder_perf_tests.cl:56-236, one pass of the while(1) frame loop */
+int oracle_fpga_perf_decoder_frame(const oracle_code *c, int num_iter, uint8_t *is_erasure, uint64_t *payload,
+                                   int *iterations)
+{
+    const int n_ldpc = c->n, k_ldpc = c->k;
+    const int num_parity_checks = n_ldpc - k_ldpc; /* :62 */
+    /* :60-61,68-69 codeword / codeword2 start as the same received frame */
+    uint8_t *er1 = (uint8_t *)malloc((size_t)n_ldpc), *er2 = (uint8_t *)malloc((size_t)n_ldpc);
+    uint64_t *sy1 = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n_ldpc), *sy2 = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)n_ldpc);
+    for (int ii = 0; ii < n_ldpc; ii++) {
+        er1[ii] = er2[ii] = is_erasure[ii];
+        sy1[ii] = sy2[ii] = payload ? payload[ii] : 0;
+    }
+    int iter_ind = 0, stop_sig = 0; /* :86-87 */
+    while (iter_ind < num_iter && stop_sig == 0) { /* :88 */
+        for (int half = 0; half < 2; half++) {     /* :98-137 on codeword, :139-176 on codeword2 */
+            uint8_t *er = half ? er2 : er1;
+            uint64_t *sy = half ? sy2 : sy1;
+            const int k0 = half ? num_parity_checks / 2 : 0, k1 = half ? num_parity_checks : num_parity_checks / 2;
+            for (int kk = k0; kk < k1; kk++) {
+                uint64_t parity_accumulator = 0;   /* :102-108 */
+                unsigned char num_erasures = 0;
+                unsigned int erasure_ind = 0;
+                for (int ii = 0; ii < VL(kk, 0); ii++) { /* :112 */
+                    const int col = VL(kk, ii + 1) - 1;  /* 1-based list (:114) */
+                    parity_accumulator ^= sy[col];       /* :116-119: erased symbols are XORed too (stored as zeros) */
+                    if (er[col] == 1) {                  /* :120-124 */
+                        num_erasures = (unsigned char)(num_erasures + er[col]);
+                        erasure_ind = (unsigned int)col;
+                    }
+                }
+                if (num_erasures == 1) { /* :126-135 */
+                    er[erasure_ind] = 0;
+                    sy[erasure_ind] = parity_accumulator;
+                }
+            }
+        }
+        int num_current_correct = 0; /* :178 */
+        for (int ii = 0; ii < n_ldpc; ii++) {
+            if (er1[ii] + er2[ii] == 1) { /* :180 one copy (not both) has it */
+                if (er1[ii]) { sy1[ii] = sy2[ii]; er1[ii] = 0; }
+                else { sy2[ii] = sy1[ii]; er2[ii] = 0; }
+                num_current_correct += 1; /* :197 */
+            } else if ((er1[ii] + er2[ii] == 0) && ii < k_ldpc) { /* :199 */
+                num_current_correct += 1;
+            }
+        }
+        if (num_current_correct == k_ldpc) stop_sig = 1; /* :205-207 */
+        iter_ind += 1;
+    }
+    int num_final_erasures = 0; /* :213-220 */
+    for (int ii = 0; ii < k_ldpc; ii++)
+        if (er1[ii] == 1) num_final_erasures += 1;
+    for (int ii = 0; ii < n_ldpc; ii++) {
+        is_erasure[ii] = er1[ii];
+        if (payload) payload[ii] = sy1[ii];
+    }
+    if (iterations) *iterations = iter_ind;
+    free(er1); free(er2); free(sy1); free(sy2);
+    return num_final_erasures;
+}
+
 void oracle_fpga_data_in_erasures(int seed, int per_numerator_div_64, int64_t count, uint8_t *erased)
 {
     const uint32_t key[4] = {1u /* tid, :69 */, (uint32_t)seed /* useed, :68 */, 0u, 0u}; /* :74 */

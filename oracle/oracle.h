@@ -119,6 +119,14 @@ void oracle_synth_erasures_bursty(uint64_t seed, int64_t frame0, int nframes, in
  * with key {1, seed} and a counter incremented before every symbol (:74-75,96-97), erased iff (rv & 0x3F) <
  * PER_numerator_div_64 (:105).  count = numFrames * n symbols, frames concatenated. */
 void oracle_fpga_data_in_erasures(int seed, int per_numerator_div_64, int64_t count, uint8_t *erased);
+/* One frame through the FPGA decoder, OpenCL/device/ldpc_erasure_decoder_perf_tests.cl:56-236: two copies of the
+ * codeword, parity checks [0, m/2) swept in order on the first copy and [m/2, m) on the second (:98-176), the copies
+ * merged after every iteration (:178-201), stop when num_current_correct == k (:205-207).  One 64-bit word per
+ * symbol stands for the 128-word payload (every word goes through the same XORs).  is_erasure / payload are updated
+ * in place to the state of the first copy after the loop; returns the number of the first k symbols still erased
+ * (:214-220, a frame error when > 0); *iterations = iter_ind. */
+int oracle_fpga_perf_decoder_frame(const oracle_code *c, int num_iter, uint8_t *is_erasure, uint64_t *payload,
+                                   int *iterations);
 void oracle_threefry4x32_20(const uint32_t ctr[4], const uint32_t key[4], uint32_t out[4]);
 
 /* ---- batch helpers for bench.py's cpu_baseline leg (single thread each; callers may fork) ------- */

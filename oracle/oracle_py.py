@@ -61,6 +61,7 @@ def lib():
     L.oracle_synth_erasures_bursty.argtypes = [C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double,
                                                C.c_double, u8p]
     L.oracle_fpga_data_in_erasures.argtypes = [C.c_int, C.c_int, C.c_int64, u8p]
+    L.oracle_fpga_perf_decoder_frame.argtypes = [C.c_void_p, C.c_int, u8p, C.c_void_p, C.POINTER(C.c_int)]
     L.oracle_threefry4x32_20.argtypes = [u32p, u32p, u32p]
     L.oracle_ldpc_decode_batch_s1.argtypes = [C.c_void_p, C.c_int, u8p, u8p, C.c_int, C.c_int, u8p, i32p, i32p, i32p]
     _LIB = L
@@ -151,6 +152,15 @@ class OracleCode:
         it = C.c_int(0)
         lib().oracle_ldpc_binary_mp_decode(self._h, recv, itenum, msg, C.byref(it))
         return msg, it.value
+
+    def fpga_perf_decoder(self, erased, num_iter, payload=None):
+        """OpenCL/device/ldpc_erasure_decoder_perf_tests.cl frame loop -> (systematic erasures left, iterations,
+        final is_erasure flags of the first copy, final payload words or None)."""
+        er = np.ascontiguousarray(erased, dtype=np.uint8).copy()
+        pl = None if payload is None else np.ascontiguousarray(payload, dtype=np.uint64).copy()
+        it = C.c_int(0)
+        left = lib().oracle_fpga_perf_decoder_frame(self._h, num_iter, er, None if pl is None else pl.ctypes.data, C.byref(it))
+        return left, it.value, er, pl
 
     def binary_hybrid(self, recv, itenum=10):
         recv = np.ascontiguousarray(recv, dtype=np.int16)

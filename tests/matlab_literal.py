@@ -305,3 +305,42 @@ def bursty_step(current_state, alpha, beta, good_transition_bias, rand_num, stat
             error_out = 1
         next_state = 0 if state_rand_num <= Prob_0_given_1 else current_state
     return error_out, next_state
+
+
+def fpga_perf_decoder(vlist, n_ldpc, k_ldpc, is_erasure, symbol, num_iter):
+    """Second, independent restatement of OpenCL/device/ldpc_erasure_decoder_perf_tests.cl:56-236 (one frame), written
+    with Python lists and 1-based Vlist rows [deg, cols...] exactly as the kernel indexes them.  `symbol` holds one
+    integer per codeword symbol (it stands for the 128 64-bit words, which all go through the same XORs)."""
+    codeword = [[symbol[i], int(is_erasure[i])] for i in range(n_ldpc)]
+    codeword2 = [[symbol[i], int(is_erasure[i])] for i in range(n_ldpc)]
+    num_parity_checks = n_ldpc - k_ldpc
+    iter_ind, stop_sig = 0, 0
+    while iter_ind < num_iter and stop_sig == 0:
+        for cw, lo, hi in ((codeword, 0, num_parity_checks // 2), (codeword2, num_parity_checks // 2, num_parity_checks)):
+            for k in range(lo, hi):
+                acc, num_erasures, erasure_ind = 0, 0, 0
+                for ii in range(vlist[k][0]):
+                    j = vlist[k][ii + 1] - 1
+                    acc ^= cw[j][0]
+                    if cw[j][1] == 1:
+                        num_erasures += 1
+                        erasure_ind = j
+                if num_erasures == 1:
+                    cw[erasure_ind][1] = 0
+                    cw[erasure_ind][0] = acc
+        num_current_correct = 0
+        for ii in range(n_ldpc):
+            ssum = codeword[ii][1] + codeword2[ii][1]
+            if ssum == 1:
+                if codeword[ii][1]:
+                    codeword[ii] = [codeword2[ii][0], 0]
+                else:
+                    codeword2[ii] = [codeword[ii][0], 0]
+                num_current_correct += 1
+            elif ssum == 0 and ii < k_ldpc:
+                num_current_correct += 1
+        if num_current_correct == k_ldpc:
+            stop_sig = 1
+        iter_ind += 1
+    num_final_erasures = sum(codeword[ii][1] for ii in range(k_ldpc))
+    return num_final_erasures, iter_ind, [c[1] for c in codeword], [c[0] for c in codeword]

@@ -339,3 +339,32 @@ def test_fpga_harness_statistics(ctx, oracle, code_ind, per64):
     blocks = erased[:, : (n // rs_n) * rs_n].reshape(nframes, n // rs_n, rs_n).sum(axis=2)
     want_rs = int((blocks > rs_n - rs_k).sum())
     assert (ldpc_err, rs_err) == (want_ldpc, want_rs)
+
+
+@pytest.mark.parametrize("code_ind,per64,num_iter", [(1, 9, 50), (1, 12, 10), (0, 23, 50), (1, 9, 2)])
+def test_fpga_perf_tests_decoder_two_halves(ctx, oracle, code_ind, per64, num_iter):
+    """The other body of the FPGA decoder kernel, OpenCL/device/ldpc_erasure_decoder_perf_tests.cl:56-236 (two copies,
+    half the checks each, merge, stop when num_current_correct == k): per-frame systematic erasures left and
+    iteration counts against the oracle's restatement, premature stops included, and the ERROR_STAT totals."""
+    code = codes.load_builtin(code_ind, binary=True)
+    p = api.code_params(code_ind)
+    n = p[0]
+    nframes, seed = 300, 777
+    ctx.data_in(n, seed, per64, code_ind, nframes)
+    ctx.ldpc_erasure_decoder_perf_tests(num_iter, code_ind)
+    left, its = ctx.fpga_frame_stats(nframes)
+    ldpc_err, _ = ctx.data_out(code_ind, nframes)
+    erased = synth.fpga_erasures(seed, per64, nframes, n)
+    oc = oracle.OracleCode(code)
+    want = [oc.fpga_perf_decoder(erased[f], num_iter)[:2] for f in range(nframes)]
+    assert np.array_equal(left, np.array([w[0] for w in want]))
+    assert np.array_equal(its, np.array([w[1] for w in want]))
+    assert ldpc_err == sum(w[0] > 0 for w in want)
+    # the in-order decoder of ldpc_erasure_decoder.cl still reports through the same per-frame interface
+    ctx.ldpc_erasure_decoder(num_iter, code_ind)
+    left2, its2 = ctx.fpga_frame_stats(nframes)
+    for f in range(0, nframes, 37):
+        recv = np.zeros(n, dtype=np.int16)
+        recv[erased[f].astype(bool)] = -1
+        msg, it = oc.binary_mp(recv, itenum=num_iter)
+        assert left2[f] == int((msg[: p[1]] == -1).sum()) and its2[f] == it

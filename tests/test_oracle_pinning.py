@@ -267,6 +267,39 @@ def test_binary_decoders(oracle, code_a):
             assert np.array_equal(mg, cw)
 
 
+def test_fpga_perf_tests_decoder_restatements_agree(oracle, code_a):
+    """a10, FPGA flavour: the C restatement of OpenCL/device/ldpc_erasure_decoder_perf_tests.cl:56-236 against a second
+    one written independently (tests/matlab_literal.py), on the reference's own (2040,1530) rows, with packet payloads:
+    64-bit words of a valid codeword lane by lane, erased packets stored as zeros (the kernel's assumption 2).
+    Includes frames in which the kernel's stop rule (num_current_correct == k, :205) fires before the systematic part
+    is complete -- the restatements must agree on those too."""
+    cb = code_a.binary()
+    oc = oracle.OracleCode(cb)
+    n, k = cb.n, cb.k
+    vlist = [[int(cb.row_ptr[r + 1] - cb.row_ptr[r])] + [int(c) + 1 for c in cb.cols[cb.row_ptr[r]:cb.row_ptr[r + 1]]] for r in range(n - k)]
+    rng = np.random.default_rng(77)
+    # a 64-bit payload word per symbol: 64 independent binary codewords side by side
+    bits = np.stack([oc.encode(rng.integers(0, 2, size=k).astype(np.uint8)) for _ in range(64)]).astype(np.uint64)
+    payload = (bits << np.arange(64, dtype=np.uint64)[:, None]).sum(axis=0).astype(np.uint64)
+    era_all = synth.fpga_erasures(5, 9, 40, n)
+    premature = 0
+    for f in range(40):
+        er = era_all[f]
+        sym = payload.copy()
+        sym[er.astype(bool)] = 0
+        for num_iter in (3, 50):   # the 50-iteration result is the one compared with the in-order decoder below
+            left, it, er_out, pl_out = oc.fpga_perf_decoder(er, num_iter, sym)
+            left2, it2, er2, pl2 = ml.fpga_perf_decoder(vlist, n, k, er, [int(x) for x in sym], num_iter)
+            assert (left, it) == (left2, it2) and np.array_equal(er_out, np.array(er2, dtype=np.uint8))
+            assert [int(x) for x in pl_out] == pl2
+            known = er_out == 0
+            assert np.array_equal(pl_out[known], payload[known])   # every recovered packet is the transmitted one
+        recv = np.zeros(n, dtype=np.int16); recv[er.astype(bool)] = -1
+        msg, _ = oc.binary_mp(recv, itenum=50)
+        premature += int(left > 0 and not (msg[:k] == -1).any())
+    assert premature > 0   # the rule does stop early on this stream (documented in DESIGN.md)
+
+
 # ---------------------------------------------------------------- a5: Reed-Solomon
 def test_rs_7_5_round_trip_like_reference_script(oracle):
     """Matlab/Test_My_RS_Decode.m:45-58 with (n,k) = (7,5): every k-subset of received positions."""
