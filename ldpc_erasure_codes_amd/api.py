@@ -35,6 +35,8 @@ EXPORTS = [
     "ldpc_amd_rs_generator", "ldpc_amd_rs_encode_batch", "ldpc_amd_rs_decode_batch", "ldpc_amd_synth_source",
     "ldpc_amd_synth_erasures_uniform", "ldpc_amd_synth_erasures_bursty", "ldpc_amd_data_in", "ldpc_amd_ldpc_erasure_decoder", "ldpc_amd_data_out",
     "ldpc_amd_ldpc_erasure_decoder_perf_tests", "ldpc_amd_fpga_frame_stats",
+    "ldpc_amd_fec_header_pack", "ldpc_amd_fec_header_unpack", "ldpc_amd_fec_packetize", "ldpc_amd_fec_rx_create",
+    "ldpc_amd_fec_rx_destroy", "ldpc_amd_fec_rx_push", "ldpc_amd_fec_rx_push_many", "ldpc_amd_fec_rx_flush", "ldpc_amd_fec_rx_dropped",
     "ldpc_amd_set_profiling", "ldpc_amd_get_profile", "ldpc_amd_selftest", "ldpc_amd_copy_probe", "ldpc_amd_gf_tables", "ldpc_amd_version",
 ]
 
@@ -92,6 +94,20 @@ def load_library():
     L.ldpc_amd_ldpc_erasure_decoder.argtypes = [vp, C.c_short, i32]
     L.ldpc_amd_ldpc_erasure_decoder_perf_tests.argtypes = [vp, C.c_short, i32]
     L.ldpc_amd_fpga_frame_stats.argtypes = [vp, C.c_long, vp, vp]
+    # host-side wire format (include/ldpc_erasure_amd_wire.h)
+    L.ldpc_amd_fec_header_pack.argtypes = [C.c_uint, C.c_uint, C.c_uint]
+    L.ldpc_amd_fec_header_pack.restype = C.c_uint64
+    L.ldpc_amd_fec_header_unpack.argtypes = [C.c_uint64, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+    L.ldpc_amd_fec_header_unpack.restype = None
+    L.ldpc_amd_fec_packetize.argtypes = [vp, C.c_long, i32, i32, C.c_uint, C.c_uint, vp]
+    L.ldpc_amd_fec_rx_create.argtypes = [i32, i32, i32, C.POINTER(vp)]
+    L.ldpc_amd_fec_rx_destroy.argtypes = [vp]
+    L.ldpc_amd_fec_rx_destroy.restype = None
+    L.ldpc_amd_fec_rx_push.argtypes = [vp, vp, vp, vp, C.POINTER(i32)]
+    L.ldpc_amd_fec_rx_flush.argtypes = [vp, vp, vp, C.POINTER(i32)]
+    L.ldpc_amd_fec_rx_push_many.argtypes = [vp, vp, C.c_long, vp, vp, vp, i32, C.POINTER(C.c_long)]
+    L.ldpc_amd_fec_rx_dropped.argtypes = [vp]
+    L.ldpc_amd_fec_rx_dropped.restype = C.c_long
     L.ldpc_amd_data_out.argtypes = [vp, vp, i32, C.c_long, C.POINTER(ErrorType)]
     L.ldpc_amd_set_profiling.argtypes = [vp, i32]
     L.ldpc_amd_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
@@ -343,3 +359,84 @@ class Context:
         st = ErrorType()
         self._check(self._L.ldpc_amd_data_out(self._h, None, code_ind, num_frames, C.byref(st)), "data_out")
         return st.num_LDPC_errors, st.num_RS_errors
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Host-side wire format (include/ldpc_erasure_amd_wire.h): FEC header, packetiser, two-buffer reassembler.
+# ---------------------------------------------------------------------------------------------------------
+def fec_header_pack(fec_class, block, symbol):
+    return int(load_library().ldpc_amd_fec_header_pack(fec_class, block, symbol))
+
+
+def fec_header_unpack(word):
+    a, b, c = C.c_uint(0), C.c_uint(0), C.c_uint(0)
+    load_library().ldpc_amd_fec_header_unpack(C.c_uint64(word), C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
+def fec_packetize(frames, fec_class=1, block0=0):
+    """frames: uint8 [F][n][S] -> packets uint8 [F*n][8+S] in transmission order."""
+    frames = np.ascontiguousarray(frames, dtype=np.uint8)
+    F, n, S = frames.shape
+    packets = np.zeros((F * n, 8 + S), dtype=np.uint8)
+    if load_library().ldpc_amd_fec_packetize(frames.ctypes.data, F, n, S, fec_class, block0, packets.ctypes.data) != 0:
+        raise LdpcAmdError("fec_packetize: bad arguments")
+    return packets
+
+
+class FecRx:
+    """Two-buffer reassembler (OpenCL/device/ldpc_erasure_decoder_with_reordering_logic.cl:44-141,214-243).
+    push(packet) / flush() return None or (block number, sym [n][S], erased [n])."""
+
+    def __init__(self, n, k, S):
+        self._L = load_library()
+        h = C.c_void_p()
+        if self._L.ldpc_amd_fec_rx_create(n, k, S, C.byref(h)) != 0:
+            raise LdpcAmdError("fec_rx_create: bad arguments")
+        self._h, self.n, self.k, self.S = h, n, k, S
+        self._sym = np.zeros((n, S), dtype=np.uint8)
+        self._er = np.zeros(n, dtype=np.uint8)
+
+    def _ret(self, rc, blk):
+        if rc < 0:
+            raise LdpcAmdError("fec_rx: bad arguments")
+        return (blk.value, self._sym.copy(), self._er.copy()) if rc == 1 else None
+
+    def push(self, packet):
+        packet = np.ascontiguousarray(packet, dtype=np.uint8)
+        assert packet.size == 8 + self.S
+        blk = C.c_int(-1)
+        return self._ret(self._L.ldpc_amd_fec_rx_push(self._h, packet.ctypes.data, self._sym.ctypes.data, self._er.ctypes.data, C.byref(blk)), blk)
+
+    def push_many(self, packets, max_blocks):
+        """packets: uint8 [P][8+S].  Returns (blocks int32 [B], sym uint8 [B][n][S], erased uint8 [B][n], consumed)."""
+        packets = np.ascontiguousarray(packets, dtype=np.uint8)
+        assert packets.ndim == 2 and packets.shape[1] == 8 + self.S
+        sym = np.zeros((max_blocks, self.n, self.S), dtype=np.uint8)
+        er = np.zeros((max_blocks, self.n), dtype=np.uint8)
+        blocks = np.zeros(max_blocks, dtype=np.int32)
+        used = C.c_long(0)
+        nb = self._L.ldpc_amd_fec_rx_push_many(self._h, packets.ctypes.data, packets.shape[0], sym.ctypes.data, er.ctypes.data,
+                                               blocks.ctypes.data, max_blocks, C.byref(used))
+        if nb < 0:
+            raise LdpcAmdError("fec_rx_push_many: bad arguments")
+        return blocks[:nb], sym[:nb], er[:nb], used.value
+
+    def flush(self):
+        blk = C.c_int(-1)
+        return self._ret(self._L.ldpc_amd_fec_rx_flush(self._h, self._sym.ctypes.data, self._er.ctypes.data, C.byref(blk)), blk)
+
+    @property
+    def dropped(self):
+        return int(self._L.ldpc_amd_fec_rx_dropped(self._h))
+
+    def close(self):
+        if self._h:
+            self._L.ldpc_amd_fec_rx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

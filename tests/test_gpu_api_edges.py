@@ -135,3 +135,39 @@ def test_cpp_host_harness_passes():
     assert "frame error rate" in r.stdout and "throughput in information bits/sec" in r.stdout
     r = subprocess.run([exe, "-e", "-c", "0"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "PASSED" in r.stdout
+
+
+def test_wire_front_end_feeds_the_decoder(ctx, code_a):
+    """SURVEY.md 8(f) rank 4 end to end: encode on the GPU -> FEC packets (header + payload) -> lossy, re-ordering
+    channel -> two-buffer reassembler (batch form) -> ldpc_amd_decode_batch -> the transmitted source symbols."""
+    h = ctx.load_builtin_code(1, codes.DEFAULT_COEF_SEED[1])
+    n, k, S, F = code_a.n, code_a.k, 16, 10
+    src = synth.source(501, 0, F, k, S)
+    cw = ctx.encode(h, src)
+    packets = api.fec_packetize(cw, 1, 252)
+    rng = np.random.default_rng(11)
+    keep = [i for i in range(len(packets)) if rng.random() >= 0.08]
+    order = sorted(keep, key=lambda i: i + rng.integers(0, 120))
+    stream = packets[order]
+    rx = api.FecRx(n, k, S)
+    blocks, sym, er, used = rx.push_many(stream, F)
+    tail = []
+    while True:
+        t = rx.flush()
+        if t is None:
+            break
+        tail.append(t)
+    assert used == len(stream) and len(blocks) + len(tail) == F
+    sym = np.concatenate([sym] + [t[1][None] for t in tail])
+    er = np.concatenate([er] + [t[2][None] for t in tail])
+    blocks = list(blocks) + [t[0] for t in tail]
+    assert blocks == [(252 + f) % 256 for f in range(F)]
+    lost = np.ones((F, n), dtype=np.uint8)
+    for i in keep:
+        lost[i // n, i % n] = 0
+    # every packet the channel lost is flagged; the only other flags are packets that arrived after their block had been
+    # closed by the 'next block has > 100 packets' rule (:139) and were therefore dropped by the receiver
+    assert not (lost & (er == 0)).any() and int(er.sum()) - int(lost.sum()) == rx.dropped
+    out, sw, res, st = ctx.decode(h, sym, er)
+    assert int(res.max()) == 0 and np.array_equal(out, cw) and np.array_equal(out[:, :k], src)
+    rx.close()

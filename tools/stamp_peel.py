@@ -17,7 +17,7 @@ def main():
     so = "/tmp/libldpc_erasure_amd_stamps.so"
     src = os.path.join(ROOT, "ldpc_erasure_codes_amd", "csrc")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-strict-aliasing",
-                           "-DLDPC_AMD_STAMPS", "-shared", "-o", so, os.path.join(src, "kernels.hip"), os.path.join(src, "api.cpp")])
+                           "-DLDPC_AMD_STAMPS", "-shared", "-o", so, os.path.join(src, "kernels.hip"), os.path.join(src, "api.cpp"), os.path.join(src, "wire.cpp")])
     import torch
     from ldpc_erasure_codes_amd import api, codes
     api.LIB_PATH = so
