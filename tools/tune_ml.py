@@ -49,6 +49,7 @@ def main():
         rs = torch.empty(F, dtype=torch.int32, device=dev)
         ref = None
         times = {v: [] for v in variants}
+        applies = {}
         ctx.set_profiling(True)
         for rnd in range(args.rounds + 1):
             for name, env in variants.items():
@@ -66,9 +67,11 @@ def main():
                     assert torch.equal(out, ref), name + " differs from the first variant"
                     continue
                 times[name].append(prof["ml"][0])
+                applies.setdefault(name, []).append(prof["apply"][0])
         ctx.set_profiling(False)
         for name, t in times.items():
-            print(f"  S={S:5d} {name:6s} ml median {statistics.median(t):7.3f} ms (min {min(t):7.3f})")
+            print(f"  S={S:5d} {name:18s} ml median {statistics.median(t):7.3f} ms (min {min(t):7.3f})   packet kernels median "
+                  f"{statistics.median(applies[name]):7.3f} ms")
         del cw, sym, out, ref
         torch.cuda.empty_cache()
     ctx.close()
