@@ -38,7 +38,7 @@ SEED_SRC, SEED_ERA = 20261004, 20261005
 
 
 SCATTER_KERNEL = "ldpc_scatter_kernel<16, 2, true, 8, false>"  # LPR=16 (256-byte row pieces), 2 pieces in flight, nt, 8 waves/SIMD, out of place
-PEEL_S1_KERNEL = "ldpc_peel_kernel<16, true>"
+PEEL_S1_KERNEL = "ldpc_peel_kernel<14, true>"
 
 
 def pmc_traffic(kernel, frames, S):

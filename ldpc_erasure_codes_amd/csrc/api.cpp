@@ -195,7 +195,7 @@ static int register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_pt
     }
     if (maxdeg > 24) { delete hc; return set_error(ctx, LDPC_AMD_EUNSUP, "row degree %d > 24 not supported", maxdeg); }
     hc->maxdeg = maxdeg;
-    const int degpad = maxdeg <= 8 ? 8 : (maxdeg <= 16 ? 16 : 24);
+    const int degpad = maxdeg <= 8 ? 8 : (maxdeg <= 14 ? 14 : (maxdeg <= 16 ? 16 : 24));  // 14: the (2040,1530) rows (13/14 entries)
     const int mpad = (m + 63) / 64 * 64;
 
     std::vector<uint32_t> edges(hc->nnz);

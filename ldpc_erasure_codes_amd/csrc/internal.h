@@ -38,7 +38,7 @@ struct DevCode {
     int n, k, m, nnz;
     int maxdeg;   // largest row degree
     int maxcoldeg;  // largest column degree (width of the per-frame padded source->target edge lists)
-    int degpad;   // template bucket the kernels are instantiated for (8, 16 or 24) >= maxdeg
+    int degpad;   // template bucket the kernels are instantiated for (8, 14, 16 or 24) >= maxdeg
     int mpad;     // m rounded up to a multiple of 64
     const uint32_t *row_ptr;  // [m+1]
     const uint32_t *edges;    // [nnz]  col | coef << 16 | log(coef) << 24   (CSR order, ascending cols)

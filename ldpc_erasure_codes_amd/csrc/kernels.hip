@@ -1108,6 +1108,7 @@ static hipError_t launch_peel_t(const PeelArgs &a, int wpb, hipStream_t s)
     }
     switch (a.code.degpad) {
         LDPC_PEEL_CASE(8)
+        LDPC_PEEL_CASE(14)
         LDPC_PEEL_CASE(16)
         LDPC_PEEL_CASE(24)
     }
@@ -1518,6 +1519,7 @@ int launch_fpga_halves(ldpc_amd_ctx *ctx, const DevCode &code, int64_t nframes, 
         hipLaunchKernelGGL(kfn, grid, dim3(64 * wpb), lds, ctx->stream, code, nframes, erased, num_iter, residual_sys, iterations, wave0, wstride); \
     }
     if (code.degpad <= 8) LDPC_FPGA_HALVES(8)
+    else if (code.degpad <= 14) LDPC_FPGA_HALVES(14)
     else if (code.degpad <= 16) LDPC_FPGA_HALVES(16)
     else LDPC_FPGA_HALVES(24)
 #undef LDPC_FPGA_HALVES
