@@ -1284,10 +1284,12 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     if (L.total > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "code too large for LDS (%d bytes)", L.total);
     {
         int best = 0;
-        for (int w = 1; w <= 16; w++) {
+        const char *env_w = getenv("LDPC_AMD_PEEL_WPB");   // diagnostic: cap the wavefronts (= frames) per workgroup
+        const int wcap = env_w ? std::max(1, std::min(16, atoi(env_w))) : 16;
+        for (int w = 1; w <= wcap; w++) {
             const PeelLds t = make_peel_lds(cd, fused, w);
             if (t.total > kLdsMax) break;
-            const int waves = std::min(32, (kLdsMax / t.total) * w);
+            const int waves = env_w ? w : std::min(32, (kLdsMax / t.total) * w);
             if (waves > best) { best = waves; wpb = w; L = t; }
         }
     }
