@@ -214,7 +214,10 @@ struct PeelArgs {
     uint8_t *ml_state;      // [slot][n]  1 = still erased
 };
 
-template <int MAXDEG, bool FUSED_S1>
+// GT ("global tables"): the code tables are read from global memory (they are shared by all frames and stay in the
+// vector L1 / L2) instead of being staged in LDS; the LDS then holds only per-frame state, which puts more frames on a
+// CU.  Chosen by the host for long S = 1 batches (launch_decode).
+template <int MAXDEG, bool FUSED_S1, bool GT>
 __global__ __launch_bounds__(1024) void ldpc_peel_kernel(PeelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -224,21 +227,23 @@ __global__ __launch_bounds__(1024) void ldpc_peel_kernel(PeelArgs a)
     const int wpb = (int)(blockDim.x >> 6);
 
     // ---- code tables -> LDS (shared by the frames of this workgroup)
-    uint16_t *ell_col = reinterpret_cast<uint16_t *>(smem + a.lds.ell_col);
-    {
+    const uint16_t *ell_col = GT ? cd.ell_col : reinterpret_cast<const uint16_t *>(smem + a.lds.ell_col);
+    const uint8_t *ell_logc = GT ? cd.ell_logc : smem + a.lds.ell_logc;
+    if (!GT) {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(cd.ell_col);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(ell_col);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(smem + a.lds.ell_col);
         const int words = (MAXDEG * mpad) >> 1;
         for (int i = (int)threadIdx.x; i < words; i += (int)blockDim.x) dst[i] = src[i];
     }
-    uint8_t *ell_logc = smem + a.lds.ell_logc;
     uint8_t *lg = smem + a.lds.lg;
     uint8_t *ex = smem + a.lds.ex;
     if (FUSED_S1) {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(cd.ell_logc);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(ell_logc);
-        const int words = (MAXDEG * mpad) >> 2;
-        for (int i = (int)threadIdx.x; i < words; i += (int)blockDim.x) dst[i] = src[i];
+        if (!GT) {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(cd.ell_logc);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(smem + a.lds.ell_logc);
+            const int words = (MAXDEG * mpad) >> 2;
+            for (int i = (int)threadIdx.x; i < words; i += (int)blockDim.x) dst[i] = src[i];
+        }
         for (int i = (int)threadIdx.x; i < 256; i += (int)blockDim.x) lg[i] = c_log[i];
         for (int i = (int)threadIdx.x; i < 512; i += (int)blockDim.x) ex[i] = c_exp[i];
     }
@@ -1068,12 +1073,12 @@ hipError_t upload_constants(hipStream_t s)
 
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
-static PeelLds make_peel_lds(const DevCode &cd, bool fused, int wpb)
+static PeelLds make_peel_lds(const DevCode &cd, bool fused, int wpb, bool gt = false)
 {
     PeelLds L{};
     int off = 0;
-    L.ell_col = off; off += align_up(cd.degpad * cd.mpad * 2, 16);
-    L.ell_logc = off; if (fused) off += align_up(cd.degpad * cd.mpad, 16);
+    L.ell_col = off; if (!gt) off += align_up(cd.degpad * cd.mpad * 2, 16);
+    L.ell_logc = off; if (fused && !gt) off += align_up(cd.degpad * cd.mpad, 16);
     L.lg = off; if (fused) off += 256;
     L.ex = off; if (fused) off += 512;
     L.wave0 = off;
@@ -1091,7 +1096,7 @@ static PeelLds make_peel_lds(const DevCode &cd, bool fused, int wpb)
     return L;
 }
 
-template <bool FUSED>
+template <bool FUSED, bool GT = false>
 static hipError_t launch_peel_t(const PeelArgs &a, int wpb, hipStream_t s)
 {
     const int grid = (int)((a.nframes + wpb - 1) / wpb);
@@ -1099,7 +1104,7 @@ static hipError_t launch_peel_t(const PeelArgs &a, int wpb, hipStream_t s)
     const size_t lds = (size_t)a.lds.total;
 #define LDPC_PEEL_CASE(D)                                                                                  \
     case D: {                                                                                              \
-        auto kfn = ldpc_peel_kernel<D, FUSED>;                                                             \
+        auto kfn = ldpc_peel_kernel<D, FUSED, GT>;                                                         \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                           \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
         if (e != hipSuccess) return e;                                                                     \
@@ -1280,6 +1285,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     // workgroup shape: the peel is latency bound (serial solve chain per frame), so pick the frames-per-workgroup
     // that puts the most wavefronts on a CU within its 160 KB of LDS (the code tables are shared by a workgroup)
     int wpb = 1;
+    bool gt = false;
     PeelLds L = make_peel_lds(cd, fused, 1);
     if (L.total > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "code too large for LDS (%d bytes)", L.total);
     {
@@ -1291,6 +1297,22 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             if (t.total > kLdsMax) break;
             const int waves = env_w ? w : std::min(32, (kLdsMax / t.total) * w);
             if (waves > best) { best = waves; wpb = w; L = t; }
+        }
+        // S = 1, long batch: with the code tables left in global memory more frames fit on a CU.  Worth it when the
+        // batch is several rounds deep anyway (a single round is latency bound and prefers the LDS tables).
+        const char *env_gt = getenv("LDPC_AMD_PEEL_GT");
+        if (fused && !env_w && !(env_gt && atoi(env_gt) == 0)) {
+            int bestg = 0, wg = 1;
+            PeelLds Lg = L;
+            for (int w = 1; w <= 16; w++) {
+                const PeelLds t = make_peel_lds(cd, fused, w, true);
+                if (t.total > kLdsMax) break;
+                const int waves = std::min(32, (kLdsMax / t.total) * w);
+                if (waves > bestg) { bestg = waves; wg = w; Lg = t; }
+            }
+            const bool deep = d.nframes >= (int64_t)3 * best * ctx->sm_count;
+            // measured: (4080,3060) 7 -> 11 frames per CU: -18 %, (4000,2000) 5 -> 8: -15 %, (2040,1530) 16 -> 21: +12 % (slower)
+            if ((env_gt && atoi(env_gt) == 1) || (deep && bestg * 20 >= best * 29)) { gt = true; wpb = wg; L = Lg; }
         }
     }
 
@@ -1316,7 +1338,8 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     }
     if (fused) {
         hipEvent_t ev = prof_begin(ctx);
-        LDPC_HIP_TRY(ctx, launch_peel_t<true>(pa, wpb, ctx->stream));
+        if (gt) { LDPC_HIP_TRY(ctx, (launch_peel_t<true, true>(pa, wpb, ctx->stream))); }
+        else { LDPC_HIP_TRY(ctx, launch_peel_t<true>(pa, wpb, ctx->stream)); }
         prof_end(ctx, LDPC_AMD_PROF_PEEL, ev);
     } else {
         const size_t hdr = (size_t)nf * 2 * 4, st = (size_t)nf * cd.m * 4, le = (size_t)nf * (cd.m + 1) * 2, iv = (size_t)nf * cd.m;
