@@ -582,6 +582,7 @@ struct ScatterArgs {
     int static_sched;         // encode: the code's static schedule / lists are used for every frame
     int inplace;              // out == sym: received rows stay where they are, only erased rows are written
     int xcd_map;              // place the slices of a frame on one XCD
+    int dyn_rows;             // streaming phase: row batches handed out through an LDS counter
     int tcap;                 // tier 1 handles frames with at most tcap steps (its LDS holds tcap accumulators)
     int nslots;               // accumulator slots in this launch's LDS (tcap in tier 1, m in tier 2 / encode)
     const int32_t *big_list;  // tier 2: [0] = count, [1..] ids of the frames with more steps; nullptr in tier 1
@@ -697,6 +698,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     for (int i = tid; i < 2048; i += nthr) mt[i] = c_mul3[i];
     for (int i = tid; i <= nlev; i += nthr) lvlend[i] = gle[i];
     for (int i = tid; i < (cd.m + 1) / 2; i += nthr) reinterpret_cast<uint32_t *>(soc)[i] = 0xFFFFFFFFu;
+    if (tid == 0) *reinterpret_cast<int *>(smem + a.lds_solved) = 0;   // row-batch counter of the streaming phase
     for (int i = tid; i < nsteps * LPR; i += nthr) reinterpret_cast<U4 *>(acc)[i] = U4{0, 0, 0, 0};
     // row kinds: 1 received, 2 erased and never solved (written as 0), 0 erased and solved in phase B (set below)
 #pragma unroll
@@ -802,20 +804,46 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         }
     };
     {
-        const int stride = nw * R * RPW;
+        // Row batches are handed out through an LDS counter (first come, first served) instead of a fixed stride: the
+        // waves of a workgroup do different amounts of accumulator work per row, and the workgroup cannot enter the
+        // level phase before its slowest wave is through.  LDPC_AMD_SCATTER_DYN=0 restores the fixed stride.
+        int *rowctr = reinterpret_cast<int *>(smem + a.lds_solved);
+        const int step = R * RPW;
         RowBatch cur, nxt;
-        int j0 = wave * R * RPW;
-        fetch(j0, cur);
-        for (; j0 < n; j0 += stride) {
-            fetch(j0 + stride, nxt);
+        if (a.dyn_rows) {
+            int j0 = 0, j1 = 0;
+            if (lane == 0) j0 = atomicAdd(rowctr, step);
+            j0 = __builtin_amdgcn_readfirstlane(j0);
+            fetch(j0, cur);
+            while (j0 < n) {
+                if (lane == 0) j1 = atomicAdd(rowctr, step);
+                j1 = __builtin_amdgcn_readfirstlane(j1);
+                fetch(j1, nxt);
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int j = j0 + r * RPW + g;
-                if (cur.kind[r] == 2 || (cur.kind[r] == 1 && !INPLACE)) stream_store16<NT>(fout + (int64_t)j * S, cur.v[r]);
-                to_slots(cur.ew[r], 0xFFFFu);
-                scatter(cur.v[r], cur.ew[r]);
+                for (int r = 0; r < R; r++) {
+                    const int j = j0 + r * RPW + g;
+                    if (cur.kind[r] == 2 || (cur.kind[r] == 1 && !INPLACE)) stream_store16<NT>(fout + (int64_t)j * S, cur.v[r]);
+                    to_slots(cur.ew[r], 0xFFFFu);
+                    scatter(cur.v[r], cur.ew[r]);
+                }
+                cur = nxt;
+                j0 = j1;
             }
-            cur = nxt;
+        } else {
+            const int stride = nw * step;
+            int j0 = wave * step;
+            fetch(j0, cur);
+            for (; j0 < n; j0 += stride) {
+                fetch(j0 + stride, nxt);
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const int j = j0 + r * RPW + g;
+                    if (cur.kind[r] == 2 || (cur.kind[r] == 1 && !INPLACE)) stream_store16<NT>(fout + (int64_t)j * S, cur.v[r]);
+                    to_slots(cur.ew[r], 0xFFFFu);
+                    scatter(cur.v[r], cur.ew[r]);
+                }
+                cur = nxt;
+            }
         }
     }
     LDPC_STAMP(13);  // scatter: streaming phase
@@ -1191,6 +1219,8 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
     const char *env_nt = getenv("LDPC_AMD_SCATTER_NT");
     const bool nt = env_nt ? atoi(env_nt) != 0 : true;
     const char *env_x = getenv("LDPC_AMD_SCATTER_XCD");
+    const char *env_d = getenv("LDPC_AMD_SCATTER_DYN");
+    sa.dyn_rows = env_d ? atoi(env_d) : 1;
     sa.xcd_map = env_x ? atoi(env_x) : 1;  // measured: 3.12 vs 3.22 ms once the set-up was shortened; =0 switches it off
     const dim3 grid((unsigned)(sa.nframes * sa.nslices));
     // tier 1

@@ -57,10 +57,12 @@ def main():
         "B128": {"LDPC_AMD_SCATTER_B": "128"},
         "B128 R4": {"LDPC_AMD_SCATTER_B": "128", "LDPC_AMD_SCATTER_R": "4"},
         "xcd1": {"LDPC_AMD_SCATTER_XCD": "1"},
+        "dyn0": {"LDPC_AMD_SCATTER_DYN": "0"},
+        "dyn1": {"LDPC_AMD_SCATTER_DYN": "1"},
     }
     if args.variants:
         variants = {k: v for k, v in variants.items() if any(x in k for x in args.variants.split(","))}
-    knobs = ["LDPC_AMD_APPLY", "LDPC_AMD_SCATTER_TIERS", "LDPC_AMD_SCATTER_NT", "LDPC_AMD_SCATTER_R", "LDPC_AMD_SCATTER_XCD", "LDPC_AMD_SCATTER_B"]
+    knobs = ["LDPC_AMD_APPLY", "LDPC_AMD_SCATTER_TIERS", "LDPC_AMD_SCATTER_NT", "LDPC_AMD_SCATTER_R", "LDPC_AMD_SCATTER_XCD", "LDPC_AMD_SCATTER_B", "LDPC_AMD_SCATTER_DYN"]
     times = {name: {"peel": [], "apply": []} for name in variants}
     ctx.set_profiling(True)
     for rnd in range(args.rounds + 1):
