@@ -38,7 +38,7 @@ SEED_SRC, SEED_ERA = 20261004, 20261005
 
 
 SCATTER_KERNEL = "ldpc_scatter_kernel<16, 2, true, 8, false>"  # LPR=16 (256-byte row pieces), 2 pieces in flight, nt, 8 waves/SIMD, out of place
-PEEL_S1_KERNEL = "ldpc_peel_kernel<14, true>"
+PEEL_S1_KERNEL = "ldpc_peel_kernel<14, true, false>"  # 14 neighbours per check, fused S = 1 apply, code tables in LDS
 
 
 def pmc_traffic(kernel, frames, S):
@@ -51,7 +51,8 @@ def pmc_traffic(kernel, frames, S):
         return None
     try:
         ks = json.load(open(path))["kernels"]
-        k = ks.get(kernel) or next(v for name, v in ks.items() if name.startswith(kernel.split("<")[0] + "<") and (S == 1) == ("true>" in name and "peel" in name))
+        k = ks.get(kernel) or next(v for name, v in ks.items() if name.startswith(kernel.split("<")[0] + "<")
+                                   and (S == 1) == ("peel" in name and name.split(",")[1].strip().startswith("true")))
     except (KeyError, ValueError, StopIteration):
         return None
     if S == 1:  # the S = 1 launches are the large ones of that kernel in the profiled run
