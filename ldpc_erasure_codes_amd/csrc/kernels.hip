@@ -586,7 +586,7 @@ struct ScatterArgs {
     int tcap;                 // tier 1 handles frames with at most tcap steps (its LDS holds tcap accumulators)
     int nslots;               // accumulator slots in this launch's LDS (tcap in tier 1, m in tier 2 / encode)
     const int32_t *big_list;  // tier 2: [0] = count, [1..] ids of the frames with more steps; nullptr in tier 1
-    int lds_acc, lds_tgt, lds_invc, lds_lvlend, lds_solved, lds_mt, lds_soc, lds_chk;
+    int lds_acc, lds_tgt, lds_invc, lds_lvlend, lds_rowctr, lds_mt, lds_soc, lds_chk;
 };
 
 __device__ __forceinline__ MulTab lds_multab(const uint32_t *mt, uint32_t c)
@@ -698,7 +698,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     for (int i = tid; i < 2048; i += nthr) mt[i] = c_mul3[i];
     for (int i = tid; i <= nlev; i += nthr) lvlend[i] = gle[i];
     for (int i = tid; i < (cd.m + 1) / 2; i += nthr) reinterpret_cast<uint32_t *>(soc)[i] = 0xFFFFFFFFu;
-    if (tid == 0) *reinterpret_cast<int *>(smem + a.lds_solved) = 0;   // row-batch counter of the streaming phase
+    if (tid == 0) *reinterpret_cast<int *>(smem + a.lds_rowctr) = 0;   // row-batch counter of the streaming phase
     for (int i = tid; i < nsteps * LPR; i += nthr) reinterpret_cast<U4 *>(acc)[i] = U4{0, 0, 0, 0};
     // row kinds: 1 received, 2 erased and never solved (written as 0), 0 erased and solved in phase B (set below)
 #pragma unroll
@@ -807,7 +807,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         // Row batches are handed out through an LDS counter (first come, first served) instead of a fixed stride: the
         // waves of a workgroup do different amounts of accumulator work per row, and the workgroup cannot enter the
         // level phase before its slowest wave is through.  LDPC_AMD_SCATTER_DYN=0 restores the fixed stride.
-        int *rowctr = reinterpret_cast<int *>(smem + a.lds_solved);
+        int *rowctr = reinterpret_cast<int *>(smem + a.lds_rowctr);
         const int step = R * RPW;
         RowBatch cur, nxt;
         if (a.dyn_rows) {
@@ -1158,7 +1158,7 @@ struct ScatterPlan {
     int tcap = 0;       // tier 1 handles frames with <= tcap steps
     bool two_tier = false;
     int lds1 = 0, lds2 = 0;                       // dynamic LDS bytes of tier 1 / tier 2
-    int o_tgt = 0, o_invc = 0, o_lvl = 0, o_sol = 0, o_mt = 0, o_soc = 0, o_chk = 0;  // offsets behind the accumulators (relative)
+    int o_tgt = 0, o_invc = 0, o_lvl = 0, o_ctr = 0, o_mt = 0, o_soc = 0, o_chk = 0;  // offsets behind the accumulators (relative)
 };
 
 static int scatter_tail_bytes(const DevCode &cd, ScatterPlan &p)
@@ -1167,7 +1167,7 @@ static int scatter_tail_bytes(const DevCode &cd, ScatterPlan &p)
     p.o_tgt = off; off += align_up(2 * cd.m, 16);
     p.o_invc = off; off += align_up(cd.m, 16);
     p.o_lvl = off; off += align_up(2 * (cd.m + 2), 16);
-    p.o_sol = off; off += align_up((cd.n + 31) / 32 * 4, 16);
+    p.o_ctr = off; off += 16;   // row-batch counter of the streaming phase
     p.o_mt = off; off += 8192;
     p.o_soc = off; off += align_up(cd.n, 16);  // row kinds
     p.o_chk = off; off += align_up(2 * (cd.m + 2), 16);  // check -> slot
@@ -1209,7 +1209,7 @@ static void scatter_set_lds(ScatterArgs &sa, const ScatterPlan &p, int nacc)
     const int base = align_up(nacc * 16 * p.lpr, 16);
     sa.lds_acc = 0;
     sa.lds_tgt = base + p.o_tgt; sa.lds_invc = base + p.o_invc; sa.lds_lvlend = base + p.o_lvl;
-    sa.lds_solved = base + p.o_sol; sa.lds_mt = base + p.o_mt; sa.lds_soc = base + p.o_soc; sa.lds_chk = base + p.o_chk;
+    sa.lds_rowctr = base + p.o_ctr; sa.lds_mt = base + p.o_mt; sa.lds_soc = base + p.o_soc; sa.lds_chk = base + p.o_chk;
 }
 
 template <int LPR, int R>
