@@ -4,7 +4,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <thread>
 
 #include "internal.h"
 #include "../../include/ldpc_erasure_amd_synth.h"
@@ -372,6 +375,8 @@ void ldpc_amd_cleanup(ldpc_amd_ctx *ctx)
     for (auto &v : ctx->prof_events)
         for (auto &pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
+    if (ctx->aux_in) (void)hipStreamDestroy(ctx->aux_in);
+    if (ctx->aux_out) (void)hipStreamDestroy(ctx->aux_out);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -442,6 +447,110 @@ int ldpc_amd_code_csr(ldpc_amd_ctx *ctx, int code, uint32_t *row_ptr, uint16_t *
     return LDPC_AMD_OK;
 }
 
+// Host buffers, large batch: the reference's three FPGA kernels (data_in / decoder / data_out, coupled by channels,
+// OpenCL/host/src/main.cpp:513-517,617-625) run concurrently; the equivalent here is a chunked pipeline in which the
+// upload of chunk c+1, the decode of chunk c and the download of chunk c-1 overlap.  Caller memory is pageable, so a
+// copy call occupies its calling thread: uploads and kernel launches are issued from this thread, downloads from a
+// helper thread, each on its own stream; device staging is double-buffered.
+static int decode_host_pipelined(ldpc_amd_ctx *ctx, HostCode *hc, DecodeArgs d, const uint8_t *sym, const uint8_t *erased,
+                                 uint8_t *out, int32_t *sweeps, int32_t *residual, int32_t *status)
+{
+    const int64_t nframes = d.nframes;
+    const size_t fbytes = (size_t)hc->n * d.S, ebytes = (size_t)hc->n;
+    const int64_t C = std::max<int64_t>(1, std::min<int64_t>(nframes, (int64_t)(((size_t)96 << 20) / fbytes)));
+    const int64_t nc = (nframes + C - 1) / C;
+    int rc;
+    if ((rc = scratch_reserve(ctx, ctx->stage_in, 2 * fbytes * C)) || (rc = scratch_reserve(ctx, ctx->stage_er, 2 * ebytes * C)) ||
+        (rc = scratch_reserve(ctx, ctx->stage_out, 2 * fbytes * C)) || (rc = scratch_reserve(ctx, ctx->stage_i32, 2 * 3 * sizeof(int32_t) * (size_t)C)))
+        return rc;
+    if (!ctx->aux_in) LDPC_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_in, hipStreamNonBlocking));
+    if (!ctx->aux_out) LDPC_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_out, hipStreamNonBlocking));
+    hipEvent_t e_in[2], e_k[2], e_free;
+    for (int b = 0; b < 2; b++) {
+        LDPC_HIP_TRY(ctx, hipEventCreateWithFlags(&e_in[b], hipEventDisableTiming));
+        LDPC_HIP_TRY(ctx, hipEventCreateWithFlags(&e_k[b], hipEventDisableTiming));
+    }
+    LDPC_HIP_TRY(ctx, hipEventCreateWithFlags(&e_free, hipEventDisableTiming));
+    // the staging buffers may still be in use by earlier work on the context's stream
+    LDPC_HIP_TRY(ctx, hipEventRecord(e_free, ctx->stream));
+    LDPC_HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_in, e_free, 0));
+
+    std::mutex mu;
+    std::condition_variable cv;
+    int64_t launched = 0, downloaded = 0;   // chunks whose decode has been enqueued / whose results are on the host
+    bool failed = false;
+    std::string helper_err;
+    const int device = ctx->device;
+    hipStream_t s_out = ctx->aux_out;
+    uint8_t *dev_out = (uint8_t *)ctx->stage_out.p;
+    int32_t *dev_i32 = (int32_t *)ctx->stage_i32.p;
+
+    std::thread helper([&]() {
+        (void)hipSetDevice(device);
+        for (int64_t c = 0; c < nc; c++) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return launched > c || failed; });
+                if (failed) return;
+            }
+            const int b = (int)(c & 1);
+            const int64_t f0 = c * C, cnt = std::min(C, nframes - f0);
+            const int32_t *i32 = dev_i32 + (size_t)b * 3 * C;
+            hipError_t e = hipStreamWaitEvent(s_out, e_k[b], 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(out + (size_t)f0 * fbytes, dev_out + (size_t)b * fbytes * C, fbytes * cnt, hipMemcpyDeviceToHost, s_out);
+            if (e == hipSuccess && sweeps) e = hipMemcpyAsync(sweeps + f0, i32, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, s_out);
+            if (e == hipSuccess && residual) e = hipMemcpyAsync(residual + f0, i32 + C, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, s_out);
+            if (e == hipSuccess && status) e = hipMemcpyAsync(status + f0, i32 + 2 * C, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, s_out);
+            if (e == hipSuccess) e = hipStreamSynchronize(s_out);
+            std::lock_guard<std::mutex> lk(mu);
+            if (e != hipSuccess) { failed = true; helper_err = hipGetErrorString(e); cv.notify_all(); return; }
+            downloaded = c + 1;
+            cv.notify_all();
+        }
+    });
+
+    int result = LDPC_AMD_OK;
+    for (int64_t c = 0; c < nc && result == LDPC_AMD_OK; c++) {
+        const int b = (int)(c & 1);
+        const int64_t f0 = c * C, cnt = std::min(C, nframes - f0);
+        uint8_t *din = (uint8_t *)ctx->stage_in.p + (size_t)b * fbytes * C, *der = (uint8_t *)ctx->stage_er.p + (size_t)b * ebytes * C;
+        hipError_t e = hipSuccess;
+        if (c >= 2) e = hipStreamWaitEvent(ctx->aux_in, e_k[b], 0);          // in[b] was read by the decode of chunk c-2
+        if (e == hipSuccess) e = hipMemcpyAsync(din, sym + (size_t)f0 * fbytes, fbytes * cnt, hipMemcpyHostToDevice, ctx->aux_in);
+        if (e == hipSuccess) e = hipMemcpyAsync(der, erased + (size_t)f0 * ebytes, ebytes * cnt, hipMemcpyHostToDevice, ctx->aux_in);
+        if (e == hipSuccess) e = hipEventRecord(e_in[b], ctx->aux_in);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, e_in[b], 0);
+        if (e != hipSuccess) { result = set_error(ctx, LDPC_AMD_EHIP, "host pipeline: %s", hipGetErrorString(e)); break; }
+        {   // out[b], i32[b] and e_k[b] belong to chunk c-2 until its results are on the host
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return downloaded >= c - 1 || failed; });
+            if (failed) break;
+        }
+        DecodeArgs dc = d;
+        dc.nframes = cnt; dc.sym = din; dc.erased = der; dc.out = dev_out + (size_t)b * fbytes * C;
+        int32_t *i32 = dev_i32 + (size_t)b * 3 * C;
+        dc.sweeps = i32; dc.residual = i32 + C; dc.status = i32 + 2 * C;
+        if ((rc = launch_decode(ctx, dc))) { result = rc; break; }
+        e = hipEventRecord(e_k[b], ctx->stream);
+        if (e != hipSuccess) { result = set_error(ctx, LDPC_AMD_EHIP, "host pipeline: %s", hipGetErrorString(e)); break; }
+        std::lock_guard<std::mutex> lk(mu);
+        launched = c + 1;
+        cv.notify_all();
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (result != LDPC_AMD_OK) failed = true;
+        cv.notify_all();
+    }
+    helper.join();
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->aux_in);
+    for (int b = 0; b < 2; b++) { (void)hipEventDestroy(e_in[b]); (void)hipEventDestroy(e_k[b]); }
+    (void)hipEventDestroy(e_free);
+    if (result == LDPC_AMD_OK && failed) result = set_error(ctx, LDPC_AMD_EHIP, "host pipeline (download): %s", helper_err.c_str());
+    return result;
+}
+
 int ldpc_amd_decode_batch(ldpc_amd_ctx *ctx, int code, int S, int64_t nframes, const uint8_t *sym,
                           const uint8_t *erased, int max_sweeps, int do_ml, uint8_t *out, int32_t *sweeps,
                           int32_t *residual, int32_t *status, unsigned flags)
@@ -465,6 +574,11 @@ int ldpc_amd_decode_batch(ldpc_amd_ctx *ctx, int code, int S, int64_t nframes, c
     }
     if (flags & LDPC_AMD_INPLACE) return set_error(ctx, LDPC_AMD_EINVAL, "LDPC_AMD_INPLACE needs LDPC_AMD_DEVICE_PTRS");
     int rc;
+    {
+        const char *env_p = getenv("LDPC_AMD_HOST_PIPELINE");
+        if (fbytes * (size_t)nframes >= ((size_t)192 << 20) && !(env_p && atoi(env_p) == 0))
+            return decode_host_pipelined(ctx, hc, d, sym, erased, out, sweeps, residual, status);
+    }
     if ((rc = scratch_reserve(ctx, ctx->stage_in, fbytes * nframes)) || (rc = scratch_reserve(ctx, ctx->stage_er, (size_t)hc->n * nframes)) ||
         (rc = scratch_reserve(ctx, ctx->stage_out, fbytes * nframes)) || (rc = scratch_reserve(ctx, ctx->stage_i32, 3 * sizeof(int32_t) * (size_t)nframes)))
         return rc;

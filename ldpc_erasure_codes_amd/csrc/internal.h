@@ -83,6 +83,7 @@ struct ldpc_amd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t aux_in = nullptr, aux_out = nullptr;   // host-pointer pipeline: H2D / D2H streams (created on first use)
     std::string err;
     std::vector<ldpc_amd::HostCode *> codes;
     std::vector<ldpc_amd::HostRs *> rs;

@@ -171,3 +171,26 @@ def test_wire_front_end_feeds_the_decoder(ctx, code_a):
     out, sw, res, st = ctx.decode(h, sym, er)
     assert int(res.max()) == 0 and np.array_equal(out, cw) and np.array_equal(out[:, :k], src)
     rx.close()
+
+
+def test_host_buffer_pipeline_matches_single_shot(ctx, code_a):
+    """Host pointers, batch above the pipeline threshold (chunked upload / decode / download from two host threads):
+    same bytes and status words as the single-shot path (LDPC_AMD_HOST_PIPELINE=0), ragged last chunk, ML frames in
+    the middle of the batch."""
+    h = ctx.load_builtin_code(1, codes.DEFAULT_COEF_SEED[1])
+    n, k, S, F = code_a.n, code_a.k, 1024, 150          # 300 MB each way: four chunks of 47/47/47/9 frames
+    src = synth.source(601, 0, F, k, S)
+    cw = ctx.encode(h, src)
+    era = synth.erasures_uniform(602, 0, F, n, 0.10)
+    era[60:70] = synth.erasures_uniform(603, 0, 10, n, 0.21)
+    sym = cw.copy()
+    sym[era.astype(bool)] = 0x77
+    os.environ["LDPC_AMD_HOST_PIPELINE"] = "0"
+    try:
+        ref = ctx.decode(h, sym, era)
+    finally:
+        os.environ.pop("LDPC_AMD_HOST_PIPELINE")
+    got = ctx.decode(h, sym, era)
+    for a, b in zip(got, ref):
+        assert np.array_equal(a, b)
+    assert int((got[3] == 1).sum()) > 0 and np.array_equal(got[0][got[3] <= 1], cw[got[3] <= 1])
