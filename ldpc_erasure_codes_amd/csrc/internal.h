@@ -45,6 +45,7 @@ struct DevCode {
     const uint16_t *ell_col;  // [degpad][mpad]  transposed padded rows, 0xFFFF = none
     const uint8_t *ell_logc;  // [degpad][mpad]  log(coef)
     const uint8_t *ell_coef;  // [degpad][mpad]  coef
+    const uint32_t *ell_pk;   // [degpad][mpad]  col | log(coef) << 16 (S = 1 kernel: one LDS read per neighbour)
     const uint8_t *enc_invc;  // [m]  inverse of the coefficient each static encode step divides by
     const uint32_t *cell;     // [n][1 << cdw_shift]  column lists: check | coef << 16, 0xFFFFFFFF = none
     int cdw_shift;            // log2 of the padded column-list width (>= maxcoldeg)

@@ -82,8 +82,9 @@ __device__ unsigned long long g_peel_stamps[16];
 // for lanes ABOVE a solving lane only -- exactly the visibility rule of the sequential loop.
 //   st[j]   : 0xFFFF erased and unknown, otherwise the dependency level of symbol j (0 = received)
 //   steps[] : (check | symbol << 16) in solve order; slvl[] the step's level (1 + max level of its inputs)
-template <int MAXDEG>
-__device__ __forceinline__ void peel_wave(const uint16_t *ell_col, int mpad, uint16_t *st, uint32_t *steps,
+// EllT: uint16_t (neighbour ids) or uint32_t (id | log(coef) << 16, the table of the S = 1 kernel)
+template <int MAXDEG, typename EllT>
+__device__ __forceinline__ void peel_wave(const EllT *ell_col, int mpad, uint16_t *st, uint32_t *steps,
                                           uint16_t *slvl, int max_sweeps, int &nsteps, int &remaining,
                                           int &sweeps, int &maxlvl)
 {
@@ -97,7 +98,7 @@ __device__ __forceinline__ void peel_wave(const uint16_t *ell_col, int mpad, uin
             // two rounds of independent LDS reads: the check's neighbour ids, then their states
             uint32_t c[MAXDEG], sv[MAXDEG];
 #pragma unroll
-            for (int t = 0; t < MAXDEG; t++) c[t] = ell_col[t * mpad + row];
+            for (int t = 0; t < MAXDEG; t++) c[t] = (uint32_t)ell_col[t * mpad + row] & 0xFFFFu;
 #pragma unroll
             for (int t = 0; t < MAXDEG; t++) sv[t] = st[c[t] == 0xFFFFu ? 0u : c[t]];
             int cnt = 0;
@@ -227,23 +228,19 @@ __global__ __launch_bounds__(1024) void ldpc_peel_kernel(PeelArgs a)
     const int wpb = (int)(blockDim.x >> 6);
 
     // ---- code tables -> LDS (shared by the frames of this workgroup)
-    const uint16_t *ell_col = GT ? cd.ell_col : reinterpret_cast<const uint16_t *>(smem + a.lds.ell_col);
-    const uint8_t *ell_logc = GT ? cd.ell_logc : smem + a.lds.ell_logc;
+    // S = 1: one 32-bit word per neighbour (id | log(coef) << 16); packets: the 16-bit ids only
+    using EllT = typename std::conditional<FUSED_S1, uint32_t, uint16_t>::type;
+    const EllT *gsrc = FUSED_S1 ? reinterpret_cast<const EllT *>(cd.ell_pk) : reinterpret_cast<const EllT *>(cd.ell_col);
+    const EllT *ell_col = GT ? gsrc : reinterpret_cast<const EllT *>(smem + a.lds.ell_col);
     if (!GT) {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(cd.ell_col);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(gsrc);
         uint32_t *dst = reinterpret_cast<uint32_t *>(smem + a.lds.ell_col);
-        const int words = (MAXDEG * mpad) >> 1;
+        const int words = (MAXDEG * mpad * (int)sizeof(EllT)) >> 2;
         for (int i = (int)threadIdx.x; i < words; i += (int)blockDim.x) dst[i] = src[i];
     }
     uint8_t *lg = smem + a.lds.lg;
     uint8_t *ex = smem + a.lds.ex;
     if (FUSED_S1) {
-        if (!GT) {
-            const uint32_t *src = reinterpret_cast<const uint32_t *>(cd.ell_logc);
-            uint32_t *dst = reinterpret_cast<uint32_t *>(smem + a.lds.ell_logc);
-            const int words = (MAXDEG * mpad) >> 2;
-            for (int i = (int)threadIdx.x; i < words; i += (int)blockDim.x) dst[i] = src[i];
-        }
         for (int i = (int)threadIdx.x; i < 256; i += (int)blockDim.x) lg[i] = c_log[i];
         for (int i = (int)threadIdx.x; i < 512; i += (int)blockDim.x) ex[i] = c_exp[i];
     }
@@ -312,7 +309,7 @@ __global__ __launch_bounds__(1024) void ldpc_peel_kernel(PeelArgs a)
 
     LDPC_STAMP(0);  // frame load
     int nsteps, sweeps, maxlvl;
-    peel_wave<MAXDEG>(ell_col, mpad, st, steps, slvl, a.max_sweeps, nsteps, remaining, sweeps, maxlvl);
+    peel_wave<MAXDEG, EllT>(ell_col, mpad, st, steps, slvl, a.max_sweeps, nsteps, remaining, sweeps, maxlvl);
     LDPC_STAMP(1);  // peeling sweeps
 
     // ---- per-frame results + hand-off of residual frames to the ML stage
@@ -368,7 +365,7 @@ __global__ __launch_bounds__(1024) void ldpc_peel_kernel(PeelArgs a)
             const uint32_t row = step & 0xFFFFu, t = step >> 16;
             int pos = 0;
 #pragma unroll
-            for (int tt = 0; tt < MAXDEG; tt++) pos = (ell_col[tt * mpad + row] == t) ? tt : pos;
+            for (int tt = 0; tt < MAXDEG; tt++) pos = (((uint32_t)ell_col[tt * mpad + row] & 0xFFFFu) == t) ? tt : pos;
             gi[i] = c_inv[cd.ell_coef[(size_t)pos * mpad + row]];
         }
         uint16_t *gl = a.sched_lvlend + f * (m + 1);
@@ -427,7 +424,11 @@ __global__ __launch_bounds__(1024) void ldpc_peel_kernel(PeelArgs a)
                 // four rounds of independent LDS reads instead of MAXDEG dependent chains
                 uint32_t c[MAXDEG], lc[MAXDEG], v[MAXDEG], lv[MAXDEG];
 #pragma unroll
-                for (int t = 0; t < MAXDEG; t++) { c[t] = ell_col[t * mpad + row]; lc[t] = ell_logc[t * mpad + row]; }
+                for (int t = 0; t < MAXDEG; t++) {
+                    const uint32_t w = (uint32_t)ell_col[t * mpad + row];
+                    c[t] = w & 0xFFFFu;
+                    lc[t] = w >> 16;   // (0 for the 16-bit table of the packet instantiation, which never gets here)
+                }
 #pragma unroll
                 for (int t = 0; t < MAXDEG; t++) v[t] = y[c[t] == 0xFFFFu ? 0u : c[t]];
 #pragma unroll
@@ -1105,8 +1106,8 @@ static PeelLds make_peel_lds(const DevCode &cd, bool fused, int wpb, bool gt = f
 {
     PeelLds L{};
     int off = 0;
-    L.ell_col = off; if (!gt) off += align_up(cd.degpad * cd.mpad * 2, 16);
-    L.ell_logc = off; if (fused && !gt) off += align_up(cd.degpad * cd.mpad, 16);
+    L.ell_col = off; if (!gt) off += align_up(cd.degpad * cd.mpad * (fused ? 4 : 2), 16);   // S = 1: id | log(coef) << 16
+    L.ell_logc = off;
     L.lg = off; if (fused) off += 256;
     L.ex = off; if (fused) off += 512;
     L.wave0 = off;
