@@ -699,7 +699,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     for (int i = tid; i < 2048; i += nthr) mt[i] = c_mul3[i];
     for (int i = tid; i <= nlev; i += nthr) lvlend[i] = gle[i];
     for (int i = tid; i < (cd.m + 1) / 2; i += nthr) reinterpret_cast<uint32_t *>(soc)[i] = 0xFFFFFFFFu;
-    if (tid == 0) *reinterpret_cast<int *>(smem + a.lds_rowctr) = 0;   // row-batch counter of the streaming phase
+    if (tid < 2) reinterpret_cast<int *>(smem + a.lds_rowctr)[tid] = 0;   // [0] row-batch counter of the streaming phase, [1] received rows
     for (int i = tid; i < nsteps * LPR; i += nthr) reinterpret_cast<U4 *>(acc)[i] = U4{0, 0, 0, 0};
     // row kinds: 1 received, 2 erased and never solved (written as 0), 0 erased and solved in phase B (set below)
 #pragma unroll
@@ -736,6 +736,38 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     }
     __syncthreads();
 
+    // List mode (a.dyn_rows == 2): the received rows are compacted into a list, so that the streaming loop below has
+    // no conditional memory operation -- every lane group loads (and stores) a row in every pass -- and the compiler
+    // can count the outstanding operations instead of waiting for all of them.  The list overwrites the row kinds,
+    // which are pulled into registers first.  Rows that were erased and are never solved are zeroed here.
+    uint16_t *rlist = reinterpret_cast<uint16_t *>(rk);
+    int nrecv = 0;
+    const bool list_mode = a.dyn_rows == 2 && n <= EPT * nthr;
+    if (list_mode) {
+        int *nrecv_p = reinterpret_cast<int *>(smem + a.lds_rowctr) + 1;
+        uint32_t kd[EPT];
+#pragma unroll
+        for (int u = 0; u < EPT; u++) {
+            const int j = tid + u * nthr;
+            kd[u] = (j < n) ? (uint32_t)rk[j] : 0u;
+        }
+        __syncthreads();
+        uint8_t *fz = a.out + f * (int64_t)n * S + (int64_t)sl * B;
+#pragma unroll
+        for (int u = 0; u < EPT; u++) {
+            const int j = tid + u * nthr;
+            const bool recv = kd[u] == 1u;
+            const uint64_t mask = __ballot(recv);
+            int base = 0;
+            if (lane == 0 && mask) base = atomicAdd(nrecv_p, __popcll(mask));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (recv) rlist[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)j;
+            if (kd[u] == 2u)
+                for (int q = 0; q < LPR; q++) stream_store16<NT>(fz + (int64_t)j * S + q * 16, U4{0, 0, 0, 0});
+        }
+        __syncthreads();
+        nrecv = *nrecv_p;
+    }
     LDPC_STAMP(12);  // scatter: set-up
     const uint8_t *fin = a.sym + f * (int64_t)a.in_rows * S + (int64_t)sl * B + gl * 16;
     uint8_t *fout = a.out + f * (int64_t)n * S + (int64_t)sl * B + gl * 16;
@@ -784,6 +816,24 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         U4 v[R];
         uint32_t ew[R][KQ];
         int kind[R];  // 0 skip (erased and solved later, or past the end), 1 received row, 2 erased and never solved
+        int row[R];   // list mode: the row a lane group holds
+    };
+    auto fetch_list = [&](int i0, RowBatch &b) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int idx = i0 + r * RPW + g;
+            const bool valid = idx < nrecv;
+            const int j = (int)rlist[valid ? idx : nrecv - 1];   // past the end: the last row again (same bytes, same place)
+            b.kind[r] = valid ? 1 : 0;
+            b.row[r] = j;
+            b.v[r] = stream_load16<NT>(fin + (int64_t)j * S);
+#pragma unroll
+            for (int q = 0; q < KQ; q++) {
+                const int e = gl + q * LPR;
+                const uint32_t w = spad[((int64_t)j << cd.cdw_shift) + (e < cdw ? e : cdw - 1)];
+                b.ew[r][q] = (valid && e < cdw) ? w : 0xFFFFFFFFu;
+            }
+        }
     };
     auto fetch = [&](int j0, RowBatch &b) {
 #pragma unroll
@@ -811,7 +861,36 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         int *rowctr = reinterpret_cast<int *>(smem + a.lds_rowctr);
         const int step = R * RPW;
         RowBatch cur, nxt;
-        if (a.dyn_rows) {
+        if (list_mode) {
+            int i0 = nrecv, i1 = 0;
+            if (nrecv > 0) {
+                if (lane == 0) i0 = atomicAdd(rowctr, step);
+                i0 = __builtin_amdgcn_readfirstlane(i0);
+            }
+            if (i0 < nrecv) {
+                auto process = [&](const RowBatch &b) {
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        if (!INPLACE) stream_store16<NT>(fout + (int64_t)b.row[r] * S, b.v[r]);
+                        uint32_t ew[KQ];
+#pragma unroll
+                        for (int q = 0; q < KQ; q++) ew[q] = b.ew[r][q];
+                        to_slots(ew, 0xFFFFu);
+                        scatter(b.v[r], ew);
+                    }
+                };
+                fetch_list(i0, cur);
+                for (;;) {   // the body has no conditional memory operation: next batch's loads, this batch's stores
+                    if (lane == 0) i1 = atomicAdd(rowctr, step);
+                    i1 = __builtin_amdgcn_readfirstlane(i1);
+                    if (i1 >= nrecv) break;
+                    fetch_list(i1, nxt);
+                    process(cur);
+                    cur = nxt;
+                }
+                process(cur);
+            }
+        } else if (a.dyn_rows) {
             int j0 = 0, j1 = 0;
             if (lane == 0) j0 = atomicAdd(rowctr, step);
             j0 = __builtin_amdgcn_readfirstlane(j0);
@@ -1170,7 +1249,7 @@ static int scatter_tail_bytes(const DevCode &cd, ScatterPlan &p)
     p.o_lvl = off; off += align_up(2 * (cd.m + 2), 16);
     p.o_ctr = off; off += 16;   // row-batch counter of the streaming phase
     p.o_mt = off; off += 8192;
-    p.o_soc = off; off += align_up(cd.n, 16);  // row kinds
+    p.o_soc = off; off += align_up(2 * cd.n, 16);  // row kinds (u8), later the list of received rows (u16)
     p.o_chk = off; off += align_up(2 * (cd.m + 2), 16);  // check -> slot
     return off;
 }

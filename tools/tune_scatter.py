@@ -59,6 +59,7 @@ def main():
         "xcd1": {"LDPC_AMD_SCATTER_XCD": "1"},
         "dyn0": {"LDPC_AMD_SCATTER_DYN": "0"},
         "dyn1": {"LDPC_AMD_SCATTER_DYN": "1"},
+        "dyn2 list": {"LDPC_AMD_SCATTER_DYN": "2"},
     }
     if args.variants:
         variants = {k: v for k, v in variants.items() if any(x in k for x in args.variants.split(","))}
