@@ -769,8 +769,13 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         nrecv = *nrecv_p;
     }
     LDPC_STAMP(12);  // scatter: set-up
-    const uint8_t *fin = a.sym + f * (int64_t)a.in_rows * S + (int64_t)sl * B + gl * 16;
-    uint8_t *fout = a.out + f * (int64_t)n * S + (int64_t)sl * B + gl * 16;
+    // Uniform 64-bit bases + 32-bit per-lane offsets (a frame slice spans n * S < 4 GB): the row addresses then cost one
+    // 32-bit multiply-add instead of 64-bit multiplies -- the streaming loop is bound by vector ALU issue, not by waits.
+    const uint8_t *fin0 = a.sym + f * (int64_t)a.in_rows * S + (int64_t)sl * B;
+    uint8_t *fout0 = a.out + f * (int64_t)n * S + (int64_t)sl * B;
+    const uint32_t lo16 = (uint32_t)gl * 16u, S32 = (uint32_t)S;
+    auto in_row = [&](int j) { return fin0 + ((uint32_t)j * S32 + lo16); };
+    auto out_row = [&](int j) { return fout0 + ((uint32_t)j * S32 + lo16); };
     // H's static column lists (check | coef << 16); the encoder's are already in (slot | coef << 16) form
     const uint32_t *spad = a.static_sched ? cd.enc_src : cd.cell;
     const bool translate = !a.static_sched;
@@ -826,11 +831,11 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
             const int j = (int)rlist[valid ? idx : nrecv - 1];   // past the end: the last row again (same bytes, same place)
             b.kind[r] = valid ? 1 : 0;
             b.row[r] = j;
-            b.v[r] = stream_load16<NT>(fin + (int64_t)j * S);
+            b.v[r] = stream_load16<NT>(in_row(j));
 #pragma unroll
             for (int q = 0; q < KQ; q++) {
                 const int e = gl + q * LPR;
-                const uint32_t w = spad[((int64_t)j << cd.cdw_shift) + (e < cdw ? e : cdw - 1)];
+                const uint32_t w = spad[((uint32_t)j << cd.cdw_shift) + (uint32_t)(e < cdw ? e : cdw - 1)];
                 b.ew[r][q] = (valid && e < cdw) ? w : 0xFFFFFFFFu;
             }
         }
@@ -845,11 +850,11 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
 #pragma unroll
             for (int q = 0; q < KQ; q++) b.ew[r][q] = 0xFFFFFFFFu;
             if (kd == 1) {
-                b.v[r] = stream_load16<NT>(fin + (int64_t)j * S);
+                b.v[r] = stream_load16<NT>(in_row(j));
 #pragma unroll
                 for (int q = 0; q < KQ; q++) {
                     const int idx = gl + q * LPR;
-                    if (idx < cdw) b.ew[r][q] = spad[((int64_t)j << cd.cdw_shift) + idx];
+                    if (idx < cdw) b.ew[r][q] = spad[((uint32_t)j << cd.cdw_shift) + (uint32_t)idx];
                 }
             }
         }
@@ -871,7 +876,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
                 auto process = [&](const RowBatch &b) {
 #pragma unroll
                     for (int r = 0; r < R; r++) {
-                        if (!INPLACE) stream_store16<NT>(fout + (int64_t)b.row[r] * S, b.v[r]);
+                        if (!INPLACE) stream_store16<NT>(out_row(b.row[r]), b.v[r]);
                         uint32_t ew[KQ];
 #pragma unroll
                         for (int q = 0; q < KQ; q++) ew[q] = b.ew[r][q];
@@ -902,7 +907,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const int j = j0 + r * RPW + g;
-                    if (cur.kind[r] == 2 || (cur.kind[r] == 1 && !INPLACE)) stream_store16<NT>(fout + (int64_t)j * S, cur.v[r]);
+                    if (cur.kind[r] == 2 || (cur.kind[r] == 1 && !INPLACE)) stream_store16<NT>(out_row(j), cur.v[r]);
                     to_slots(cur.ew[r], 0xFFFFu);
                     scatter(cur.v[r], cur.ew[r]);
                 }
@@ -918,7 +923,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const int j = j0 + r * RPW + g;
-                    if (cur.kind[r] == 2 || (cur.kind[r] == 1 && !INPLACE)) stream_store16<NT>(fout + (int64_t)j * S, cur.v[r]);
+                    if (cur.kind[r] == 2 || (cur.kind[r] == 1 && !INPLACE)) stream_store16<NT>(out_row(j), cur.v[r]);
                     to_slots(cur.ew[r], 0xFFFFu);
                     scatter(cur.v[r], cur.ew[r]);
                 }
@@ -944,7 +949,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
 #pragma unroll
                 for (int q = 0; q < KQ; q++) {
                     const int idx = gl + q * LPR;
-                    if (idx < cdw) ew[q] = LL ? slist[s * cdw + idx] : spad[((int64_t)t << cd.cdw_shift) + idx];
+                    if (idx < cdw) ew[q] = LL ? slist[s * cdw + idx] : spad[((uint32_t)t << cd.cdw_shift) + (uint32_t)idx];
                 }
             }
         };
@@ -966,7 +971,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
                     const int t = tgt[s];
                     const U4 a16 = *reinterpret_cast<const U4 *>(acc + (size_t)s * B + gl * 16);
                     val = gfmul16(lds_multab(mt, invc[s]), a16);
-                    stream_store16<NT>(fout + (int64_t)t * S, val);
+                    stream_store16<NT>(out_row(t), val);
                 }
                 to_slots(ew, (s < s1) ? (uint32_t)s : 0xFFFFu);
                 scatter(val, ew);
@@ -1257,6 +1262,7 @@ static int scatter_tail_bytes(const DevCode &cd, ScatterPlan &p)
 static ScatterPlan plan_scatter(const DevCode &cd, int S)
 {
     ScatterPlan p;
+    if ((uint64_t)cd.n * (uint64_t)S >= (1ull << 32)) return p;   // the kernel addresses a frame with 32-bit offsets
     int B = 256;
     const char *env_b = getenv("LDPC_AMD_SCATTER_B");  // A/B knob: bytes of every row per workgroup
     if (env_b && (atoi(env_b) == 128 || atoi(env_b) == 64)) B = atoi(env_b);
