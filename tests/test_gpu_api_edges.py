@@ -194,3 +194,40 @@ def test_host_buffer_pipeline_matches_single_shot(ctx, code_a):
     for a, b in zip(got, ref):
         assert np.array_equal(a, b)
     assert int((got[3] == 1).sum()) > 0 and np.array_equal(got[0][got[3] <= 1], cw[got[3] <= 1])
+
+
+def test_two_contexts_from_two_threads(oracle, code_a):
+    """SURVEY.md 8(b) threading row: a handle is self-contained (own stream, own workspaces, no library-global state
+    besides the constant tables), so two handles may be driven from two host threads at the same time."""
+    import threading
+    results = {}
+
+    def worker(tag, seed, per):
+        c = api.Context(0)
+        try:
+            h = c.load_builtin_code(1, codes.DEFAULT_COEF_SEED[1])
+            F = 96
+            src = synth.source(seed, 0, F, code_a.k, 16)
+            cw = c.encode(h, src)
+            era = synth.erasures_uniform(seed + 1, 0, F, code_a.n, per)
+            sym = cw.copy()
+            sym[era.astype(bool)] = 0x11
+            for _ in range(4):
+                out, sw, res, st = c.decode(h, sym, era)
+            results[tag] = (cw, out, sw, res, st, era, sym)
+        finally:
+            c.close()
+
+    ts = [threading.Thread(target=worker, args=("a", 700, 0.10)), threading.Thread(target=worker, args=("b", 800, 0.20))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert set(results) == {"a", "b"}
+    oc = oracle.OracleCode(code_a)
+    for tag, (cw, out, sw, res, st, era, sym) in results.items():
+        ok = st <= 1
+        assert ok.any() and np.array_equal(out[ok], cw[ok])
+        for f in (0, 17, 95):
+            o_out, _, o_it, info, rc = oc.decode_packets(sym[f], era[f])
+            assert sw[f] == o_it and res[f] == info[0] and np.array_equal(out[f], o_out)
