@@ -114,8 +114,9 @@ int ldpc_amd_encode_batch(ldpc_amd_ctx *ctx, int code, int S, int64_t nframes, c
  * ldpc_amd_rs_decode_batch is the batched  Msg = My_RS_Decode(recv_vec_ind, recv_vec_gf256_val, m, n, k,
  * Prim_poly, G, log_lookup)  (Matlab/My_RS_Decode.m:14; table version
  * Matlab/My_RS_Decode_Optimize_With_GFTables.m:15):
- *   recv_idx [nblocks][k]     uint16  0-BASED ascending positions of the first k received symbols
- *                                     (Matlab/ReedSolomonErasureCodes.m:80-81)
+ *   recv_idx [nblocks][k]     uint16  0-BASED strictly ascending positions (< n) of the first k received symbols
+ *                                     (Matlab/ReedSolomonErasureCodes.m:80-81).  Host pointers: a violation returns
+ *                                     LDPC_AMD_EINVAL; LDPC_AMD_DEVICE_PTRS: the offending block decodes to zeros.
  *   recv_val [nblocks][k][S]  uint8   their values;   msg [nblocks][k][S] the recovered source block. */
 int ldpc_amd_rs_create(ldpc_amd_ctx *ctx, int n, int k);
 int ldpc_amd_rs_generator(ldpc_amd_ctx *ctx, int rs, uint8_t *g /* [k][n], host */);
@@ -152,13 +153,17 @@ typedef struct { /* error_type, OpenCL/device/ldpc_erasure_decoder_top.cl:46-49 
     int num_RS_errors;
 } ldpc_amd_error_type;
 /* data_in(global symbol_type*, ushort nldpc, int seed, int PER_numerator_div_64, int code_ind, long numFrames)
- * (ldpc_erasure_decoder_top.cl:58-65): draws numFrames*n erasure flags with the kernel's own generator
- * (threefry4x32-20, key {1, seed}, counter incremented per symbol, erased iff (rv & 0x3F) < PER_numerator, :74-110),
- * payload all-zero (the all-zero codeword, :77-82). data_in may be NULL (the FPGA kernel never reads it). */
+ * (ldpc_erasure_decoder_top.cl:58-65): the source of numFrames*n erasure flags from the kernel's own generator
+ * (threefry4x32-20, key {1, seed}, 32-bit counter incremented per symbol, erased iff (rv & 0x3F) < PER_numerator,
+ * :74-110), payload all-zero (the all-zero codeword, :77-82). data_in may be NULL (the FPGA kernel never reads it).
+ * Like the FPGA kernel -- a frame loop feeding a channel -- the call materialises nothing: it arms the source, and the
+ * decoder call draws the stream chunk by chunk (memory O(chunk), so N_T = 1e6 ... 2e8 of the paper's Table I runs). */
 int ldpc_amd_data_in(ldpc_amd_ctx *ctx, const ldpc_amd_symbol_type *data_in, unsigned short nldpc, int seed,
                      int PER_numerator_div_64, int code_ind, long numFrames);
 /* ldpc_erasure_decoder(short num_iter, int code_ind) (ldpc_erasure_decoder_perf_tests.cl:30): decodes the
- * frames produced by the last ldpc_amd_data_in with the binary packet-XOR message-passing decoder. */
+ * frames of the last ldpc_amd_data_in with the binary packet-XOR message-passing decoder, frame loop like :52-238:
+ * chunk by chunk  source -> decode -> running counters {num_frame_errors, num_RS_frame_errors} (:46-47,70-80,229-236).
+ * Asynchronous on the context's stream; ldpc_amd_data_out synchronises. */
 int ldpc_amd_ldpc_erasure_decoder(ldpc_amd_ctx *ctx, short num_iter, int code_ind);
 /* The reference holds two bodies for that kernel.  ldpc_amd_ldpc_erasure_decoder follows the one the top-level design
  * includes (ldpc_erasure_decoder_top.cl:161 -> ldpc_erasure_decoder.cl:24-105: num_iter in-order sweeps over all
@@ -169,10 +174,12 @@ int ldpc_amd_ldpc_erasure_decoder(ldpc_amd_ctx *ctx, short num_iter, int code_in
 int ldpc_amd_ldpc_erasure_decoder_perf_tests(ldpc_amd_ctx *ctx, short num_iter, int code_ind);
 /* Per-frame results of the last of the two decoder calls (host pointers, either may be NULL): systematic symbols
  * still erased (:213-220, the frame-error criterion) and iterations run.  No FPGA counterpart (the FPGA streams only
- * the running error counters); exists so that tests can compare frame by frame. */
+ * the running error counters); exists so that tests can compare frame by frame.  Kept for runs of up to 2^22 frames
+ * (LDPC_AMD_EUNSUP beyond); LDPC_AMD_EINVAL unless a decoder call ran over exactly the last data_in's frames. */
 int ldpc_amd_fpga_frame_stats(ldpc_amd_ctx *ctx, long numFrames, int32_t *residual_sys, int32_t *iterations);
-/* data_out(global symbol_type*, int code_ind, long numFrames) (ldpc_erasure_decoder_top.cl:124-127): collects
- * the frame-error counters (ERROR_STAT); data_out, if not NULL, receives the first k symbols of the last frame. */
+/* data_out(global symbol_type*, int code_ind, long numFrames) (ldpc_erasure_decoder_top.cl:124-127): waits for the
+ * run and collects the frame-error counters (ERROR_STAT); data_out, if not NULL, receives the first k symbols of the
+ * last frame.  LDPC_AMD_EINVAL unless a decoder call ran since the last data_in with the same code_ind / numFrames. */
 int ldpc_amd_data_out(ldpc_amd_ctx *ctx, ldpc_amd_symbol_type *data_out, int code_ind, long numFrames,
                       ldpc_amd_error_type *stats);
 

@@ -17,24 +17,26 @@ namespace ldpc_amd {
 // ------------------------------------------------------------------------------------------------
 // GF(256) host tables (poly 0x171)
 // ------------------------------------------------------------------------------------------------
+static GfHost build_gf_host()
+{
+    GfHost g;
+    memset(&g, 0, sizeof(g));
+    int x = 1;
+    for (int i = 0; i < 255; i++) {
+        g.exp[i] = (uint8_t)x;
+        g.log[x] = (uint8_t)i;
+        x <<= 1;
+        if (x & 0x100) x ^= kPrimPoly;
+    }
+    for (int i = 255; i < 512; i++) g.exp[i] = g.exp[i - 255];
+    g.inv[0] = 0;
+    for (int a = 1; a < 256; a++) g.inv[a] = g.exp[(255 - g.log[a]) % 255];
+    return g;
+}
+
 const GfHost &gf_host()
 {
-    static GfHost g;
-    static bool built = false;
-    if (!built) {
-        memset(&g, 0, sizeof(g));
-        int x = 1;
-        for (int i = 0; i < 255; i++) {
-            g.exp[i] = (uint8_t)x;
-            g.log[x] = (uint8_t)i;
-            x <<= 1;
-            if (x & 0x100) x ^= kPrimPoly;
-        }
-        for (int i = 255; i < 512; i++) g.exp[i] = g.exp[i - 255];
-        g.inv[0] = 0;
-        for (int a = 1; a < 256; a++) g.inv[a] = g.exp[(255 - g.log[a]) % 255];
-        built = true;
-    }
+    static const GfHost g = build_gf_host();   // C++11 magic static: built once, safe under concurrent first use
     return g;
 }
 
@@ -75,6 +77,8 @@ int scratch_reserve(ldpc_amd_ctx *ctx, Scratch &s, size_t bytes)
     if (s.p) {
         // pending work may still use the old block
         hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess && ctx->aux_in) e = hipStreamSynchronize(ctx->aux_in);
+        if (e == hipSuccess && ctx->aux_out) e = hipStreamSynchronize(ctx->aux_out);
         if (e != hipSuccess) return set_error(ctx, LDPC_AMD_EHIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
         (void)hipFree(s.p);
         s.p = nullptr;
@@ -377,6 +381,8 @@ void ldpc_amd_cleanup(ldpc_amd_ctx *ctx)
     for (auto &v : ctx->prof_events)
         for (auto &pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->pipe_events)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->aux_in) (void)hipStreamDestroy(ctx->aux_in);
     if (ctx->aux_out) (void)hipStreamDestroy(ctx->aux_out);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
@@ -388,7 +394,10 @@ const char *ldpc_amd_last_error(const ldpc_amd_ctx *ctx) { return ctx ? ctx->err
 int ldpc_amd_set_stream(ldpc_amd_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return LDPC_AMD_EINVAL;
+    (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->aux_in) (void)hipStreamSynchronize(ctx->aux_in);
+    if (ctx->aux_out) (void)hipStreamSynchronize(ctx->aux_out);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
@@ -467,12 +476,11 @@ static int decode_host_pipelined(ldpc_amd_ctx *ctx, HostCode *hc, DecodeArgs d, 
         return rc;
     if (!ctx->aux_in) LDPC_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_in, hipStreamNonBlocking));
     if (!ctx->aux_out) LDPC_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_out, hipStreamNonBlocking));
-    hipEvent_t e_in[2], e_k[2], e_free;
-    for (int b = 0; b < 2; b++) {
-        LDPC_HIP_TRY(ctx, hipEventCreateWithFlags(&e_in[b], hipEventDisableTiming));
-        LDPC_HIP_TRY(ctx, hipEventCreateWithFlags(&e_k[b], hipEventDisableTiming));
-    }
-    LDPC_HIP_TRY(ctx, hipEventCreateWithFlags(&e_free, hipEventDisableTiming));
+    // the five events live in the context (created once, destroyed by ldpc_amd_cleanup): no error path leaks them
+    for (int i = 0; i < 5; i++)
+        if (!ctx->pipe_events[i]) LDPC_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pipe_events[i], hipEventDisableTiming));
+    hipEvent_t e_in[2] = {ctx->pipe_events[0], ctx->pipe_events[1]}, e_k[2] = {ctx->pipe_events[2], ctx->pipe_events[3]};
+    hipEvent_t e_free = ctx->pipe_events[4];
     // the staging buffers may still be in use by earlier work on the context's stream
     LDPC_HIP_TRY(ctx, hipEventRecord(e_free, ctx->stream));
     LDPC_HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_in, e_free, 0));
@@ -487,7 +495,8 @@ static int decode_host_pipelined(ldpc_amd_ctx *ctx, HostCode *hc, DecodeArgs d, 
     uint8_t *dev_out = (uint8_t *)ctx->stage_out.p;
     int32_t *dev_i32 = (int32_t *)ctx->stage_i32.p;
 
-    std::thread helper([&]() {
+    std::thread helper;
+    auto helper_body = [&]() {
         (void)hipSetDevice(device);
         for (int64_t c = 0; c < nc; c++) {
             {
@@ -509,7 +518,12 @@ static int decode_host_pipelined(ldpc_amd_ctx *ctx, HostCode *hc, DecodeArgs d, 
             downloaded = c + 1;
             cv.notify_all();
         }
-    });
+    };
+    try {
+        helper = std::thread(helper_body);
+    } catch (...) {   // std::system_error must not cross the C ABI
+        return set_error(ctx, LDPC_AMD_ENOMEM, "host pipeline: could not start the download thread");
+    }
 
     int result = LDPC_AMD_OK;
     for (int64_t c = 0; c < nc && result == LDPC_AMD_OK; c++) {
@@ -547,8 +561,7 @@ static int decode_host_pipelined(ldpc_amd_ctx *ctx, HostCode *hc, DecodeArgs d, 
     helper.join();
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->aux_in);
-    for (int b = 0; b < 2; b++) { (void)hipEventDestroy(e_in[b]); (void)hipEventDestroy(e_k[b]); }
-    (void)hipEventDestroy(e_free);
+    (void)hipStreamSynchronize(ctx->aux_out);
     if (result == LDPC_AMD_OK && failed) result = set_error(ctx, LDPC_AMD_EHIP, "host pipeline (download): %s", helper_err.c_str());
     return result;
 }
@@ -732,6 +745,14 @@ int ldpc_amd_rs_decode_batch(ldpc_amd_ctx *ctx, int rs, int S, int64_t nblocks, 
     if (!recv_idx || !recv_val || !msg) return set_error(ctx, LDPC_AMD_EINVAL, "null data pointer");
     LDPC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (flags & LDPC_AMD_DEVICE_PTRS) return launch_rs_decode(ctx, *r, S, nblocks, recv_idx, recv_val, msg);
+    // host pointers: the positions can be checked here (with device pointers the kernels check per block and decode a
+    // malformed block to zeros)
+    for (int64_t b = 0; b < nblocks; b++) {
+        const uint16_t *ix = recv_idx + b * r->k;
+        for (int t = 0; t < r->k; t++)
+            if (ix[t] >= r->n || (t > 0 && ix[t - 1] >= ix[t]))
+                return set_error(ctx, LDPC_AMD_EINVAL, "rs_decode: block %lld: recv_idx must be < n and strictly ascending (entry %d)", (long long)b, t);
+    }
     const size_t vb = (size_t)r->k * S * nblocks, xb = (size_t)r->k * 2 * nblocks;
     int rc;
     if ((rc = scratch_reserve(ctx, ctx->stage_in, vb)) || (rc = scratch_reserve(ctx, ctx->stage_er, xb)) ||
@@ -785,6 +806,16 @@ static int fpga_code(ldpc_amd_ctx *ctx, int code_ind)
     return ctx->fpga_binary_code[code_ind];
 }
 
+// Frames per chunk of the streamed run (LDPC_AMD_FPGA_CHUNK overrides it: tests use small chunks to cross chunk borders).
+static long fpga_chunk_frames()
+{
+    const char *e = getenv("LDPC_AMD_FPGA_CHUNK");
+    const long v = e ? atol(e) : 0;
+    return v > 0 ? v : 65536;
+}
+// Runs up to this many frames keep their per-frame results for ldpc_amd_fpga_frame_stats (8 bytes per frame).
+static const long kFpgaKeepFrames = 1l << 22;
+
 int ldpc_amd_data_in(ldpc_amd_ctx *ctx, const ldpc_amd_symbol_type *data_in, unsigned short nldpc, int seed,
                      int PER_numerator_div_64, int code_ind, long numFrames)
 {
@@ -794,61 +825,80 @@ int ldpc_amd_data_in(ldpc_amd_ctx *ctx, const ldpc_amd_symbol_type *data_in, uns
     if (!b) return set_error(ctx, LDPC_AMD_ENOCODE, "no built-in code with index %d", code_ind);
     if (numFrames < 0) return set_error(ctx, LDPC_AMD_EINVAL, "numFrames < 0");
     (void)nldpc;  // the kernel takes n from ldpc_params[code_ind] (ldpc_erasure_decoder_top.cl:70-71), nldpc is only printed
-    LDPC_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc;
-    if ((rc = scratch_reserve(ctx, ctx->fpga_erased, (size_t)std::max<long>(numFrames, 1) * b->n))) return rc;
-    ctx->fpga_frames = numFrames; ctx->fpga_code_ind = code_ind; ctx->fpga_per64 = PER_numerator_div_64;
-    // erased iff (rv & 0x3F) < PER_numerator_div_64 (:105), rv from threefry4x32 with key {1, seed} and the running
-    // symbol counter (:74-75,96-98): the FPGA's own erasure stream for this seed
-    return launch_synth_fpga(ctx, (uint32_t)seed, (int64_t)numFrames * b->n, PER_numerator_div_64, (uint8_t *)ctx->fpga_erased.p);
+    // The FPGA source is a frame loop feeding a channel (:84-117): nothing is materialised.  The erasure stream is a pure
+    // function of (seed, symbol index), so the source is only armed here and its symbols are drawn chunk by chunk inside
+    // the decoder call, the way the decoder kernel pulls them from LDPC_DEC_DIN.
+    ctx->fpga_frames = numFrames; ctx->fpga_code_ind = code_ind; ctx->fpga_per64 = PER_numerator_div_64; ctx->fpga_seed = seed;
+    ctx->fpga_decoded = -1; ctx->fpga_kept = false;
+    return LDPC_AMD_OK;
 }
 
-int ldpc_amd_ldpc_erasure_decoder(ldpc_amd_ctx *ctx, short num_iter, int code_ind)
+// The streamed run: for every chunk of frames  draw the flags (data_in) -> decode -> add to the two running counters
+// (num_frame_errors / num_RS_frame_errors of ldpc_erasure_decoder_perf_tests.cl:46-47,70-80,229-236).  O(chunk) memory,
+// everything enqueued on the context's stream; ldpc_amd_data_out synchronises.
+static int fpga_run(ldpc_amd_ctx *ctx, short num_iter, int code_ind, bool halves)
 {
     if (!ctx) return LDPC_AMD_EINVAL;
-    if (ctx->fpga_code_ind != code_ind) return set_error(ctx, LDPC_AMD_EINVAL, "ldpc_amd_data_in was not called for code_ind %d", code_ind);
+    if (ctx->fpga_frames < 0 || ctx->fpga_code_ind != code_ind)
+        return set_error(ctx, LDPC_AMD_EINVAL, "ldpc_amd_data_in was not called for code_ind %d", code_ind);
+    if (num_iter < 1) return set_error(ctx, LDPC_AMD_EINVAL, "num_iter must be >= 1");
+    LDPC_HIP_TRY(ctx, hipSetDevice(ctx->device));
     int h = fpga_code(ctx, code_ind);
     if (h < 0) return h;
     HostCode *hc = ctx->codes[h];
+    const BuiltinCode *b = find_builtin(code_ind);
     const long nf = ctx->fpga_frames;
-    if (nf == 0) return LDPC_AMD_OK;
+    const long C = std::min<long>(std::max<long>(nf, 1), fpga_chunk_frames());
+    const bool keep = nf <= kFpgaKeepFrames;
+    const long slots = keep ? std::max<long>(nf, 1) : C;
+    ctx->fpga_decoded = -1;
     int rc;
-    if ((rc = scratch_reserve(ctx, ctx->fpga_stats, sizeof(int32_t) * (size_t)(2 * nf + 16)))) return rc;
-    // flags-only decode: the payload is the all-zero codeword, only the erasure pattern matters
-    DecodeArgs d{};
-    d.code = hc->dev; d.S = 16; d.nframes = nf; d.in_rows = hc->n; d.max_sweeps = num_iter; d.do_ml = 0;
-    d.erased = (const uint8_t *)ctx->fpga_erased.p;
-    d.flags_only = 1;
-    d.residual_sys = (int32_t *)ctx->fpga_stats.p + 16;
-    d.sweeps = (int32_t *)ctx->fpga_stats.p + 16 + nf;
-    return launch_decode(ctx, d);
+    if ((rc = scratch_reserve(ctx, ctx->fpga_erased, (size_t)C * hc->n))) return rc;
+    if ((rc = scratch_reserve(ctx, ctx->fpga_stats, 64 + sizeof(int32_t) * 2 * (size_t)slots))) return rc;
+    unsigned long long *counters = (unsigned long long *)ctx->fpga_stats.p;
+    int32_t *res_base = (int32_t *)((unsigned char *)ctx->fpga_stats.p + 64), *it_base = res_base + slots;
+    LDPC_HIP_TRY(ctx, hipMemsetAsync(counters, 0, 64, ctx->stream));
+    uint8_t *flags = (uint8_t *)ctx->fpga_erased.p;
+    for (long f0 = 0; f0 < nf; f0 += C) {
+        const long cnt = std::min(C, nf - f0);
+        int32_t *res = keep ? res_base + f0 : res_base, *its = keep ? it_base + f0 : it_base;
+        // erased iff (rv & 0x3F) < PER_numerator_div_64 (ldpc_erasure_decoder_top.cl:105), rv from threefry4x32 with key
+        // {1, seed} and the running symbol counter (:74-75,96-98): the FPGA's own erasure stream for this seed
+        if ((rc = launch_synth_fpga(ctx, (uint32_t)ctx->fpga_seed, (uint64_t)f0 * (uint64_t)hc->n, (int64_t)cnt * hc->n, ctx->fpga_per64, flags)))
+            return rc;
+        if (halves) {
+            if ((rc = launch_fpga_halves(ctx, hc->dev, cnt, flags, num_iter, res, its))) return rc;
+        } else {
+            // flags-only decode: the payload is the all-zero codeword, only the erasure pattern matters
+            DecodeArgs d{};
+            d.code = hc->dev; d.S = 16; d.nframes = cnt; d.in_rows = hc->n; d.max_sweeps = num_iter; d.do_ml = 0;
+            d.erased = flags; d.flags_only = 1; d.residual_sys = res; d.sweeps = its;
+            if ((rc = launch_decode(ctx, d))) return rc;
+        }
+        if ((rc = launch_fpga_stats(ctx, hc->dev, b->rs_n, b->rs_k, cnt, flags, res, counters))) return rc;
+    }
+    ctx->fpga_decoded = nf;
+    ctx->fpga_kept = keep;
+    return LDPC_AMD_OK;
 }
 
-int ldpc_amd_ldpc_erasure_decoder_perf_tests(ldpc_amd_ctx *ctx, short num_iter, int code_ind)
-{
-    if (!ctx) return LDPC_AMD_EINVAL;
-    if (ctx->fpga_code_ind != code_ind) return set_error(ctx, LDPC_AMD_EINVAL, "ldpc_amd_data_in was not called for code_ind %d", code_ind);
-    int h = fpga_code(ctx, code_ind);
-    if (h < 0) return h;
-    HostCode *hc = ctx->codes[h];
-    const long nf = ctx->fpga_frames;
-    if (nf == 0) return LDPC_AMD_OK;
-    int rc;
-    if ((rc = scratch_reserve(ctx, ctx->fpga_stats, sizeof(int32_t) * (size_t)(2 * nf + 16)))) return rc;
-    LDPC_HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int32_t *base = (int32_t *)ctx->fpga_stats.p;
-    return launch_fpga_halves(ctx, hc->dev, nf, (const uint8_t *)ctx->fpga_erased.p, num_iter, base + 16, base + 16 + nf);
-}
+int ldpc_amd_ldpc_erasure_decoder(ldpc_amd_ctx *ctx, short num_iter, int code_ind) { return fpga_run(ctx, num_iter, code_ind, false); }
+
+int ldpc_amd_ldpc_erasure_decoder_perf_tests(ldpc_amd_ctx *ctx, short num_iter, int code_ind) { return fpga_run(ctx, num_iter, code_ind, true); }
 
 int ldpc_amd_fpga_frame_stats(ldpc_amd_ctx *ctx, long numFrames, int32_t *residual_sys, int32_t *iterations)
 {
     if (!ctx) return LDPC_AMD_EINVAL;
-    if (numFrames != ctx->fpga_frames || !ctx->fpga_stats.p)
-        return set_error(ctx, LDPC_AMD_EINVAL, "fpga_frame_stats: no decoded batch of %ld frames", numFrames);
+    if (numFrames < 0 || numFrames != ctx->fpga_frames || ctx->fpga_decoded != numFrames)
+        return set_error(ctx, LDPC_AMD_EINVAL, "fpga_frame_stats: no decoded run of %ld frames (last data_in: %ld, decoded: %ld)",
+                         numFrames, ctx->fpga_frames, ctx->fpga_decoded);
     if (numFrames == 0) return LDPC_AMD_OK;
-    const int32_t *base = (const int32_t *)ctx->fpga_stats.p;
-    if (residual_sys) LDPC_HIP_TRY(ctx, hipMemcpyAsync(residual_sys, base + 16, sizeof(int32_t) * (size_t)numFrames, hipMemcpyDeviceToHost, ctx->stream));
-    if (iterations) LDPC_HIP_TRY(ctx, hipMemcpyAsync(iterations, base + 16 + numFrames, sizeof(int32_t) * (size_t)numFrames, hipMemcpyDeviceToHost, ctx->stream));
+    if (!ctx->fpga_kept)
+        return set_error(ctx, LDPC_AMD_EUNSUP, "fpga_frame_stats: per-frame results are kept for runs of up to %ld frames", kFpgaKeepFrames);
+    LDPC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int32_t *res = (const int32_t *)((const unsigned char *)ctx->fpga_stats.p + 64);
+    if (residual_sys) LDPC_HIP_TRY(ctx, hipMemcpyAsync(residual_sys, res, sizeof(int32_t) * (size_t)numFrames, hipMemcpyDeviceToHost, ctx->stream));
+    if (iterations) LDPC_HIP_TRY(ctx, hipMemcpyAsync(iterations, res + numFrames, sizeof(int32_t) * (size_t)numFrames, hipMemcpyDeviceToHost, ctx->stream));
     LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return LDPC_AMD_OK;
 }
@@ -857,21 +907,20 @@ int ldpc_amd_data_out(ldpc_amd_ctx *ctx, ldpc_amd_symbol_type *data_out, int cod
                       ldpc_amd_error_type *stats)
 {
     if (!ctx) return LDPC_AMD_EINVAL;
-    if (ctx->fpga_code_ind != code_ind || numFrames != ctx->fpga_frames)
+    if (ctx->fpga_code_ind != code_ind || numFrames < 0 || numFrames != ctx->fpga_frames)
         return set_error(ctx, LDPC_AMD_EINVAL, "data_out arguments do not match the last data_in call");
+    if (ctx->fpga_decoded != numFrames)
+        return set_error(ctx, LDPC_AMD_EINVAL, "data_out: no decoder call since the last data_in (the FPGA's data_out would block on ERROR_STAT)");
     const BuiltinCode *b = find_builtin(code_ind);
-    int h = fpga_code(ctx, code_ind);
-    if (h < 0) return h;
-    HostCode *hc = ctx->codes[h];
-    int32_t host[2] = {0, 0};
+    if (!b) return set_error(ctx, LDPC_AMD_ENOCODE, "no built-in code with index %d", code_ind);
+    LDPC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned long long host[2] = {0, 0};
     if (numFrames > 0) {
-        int32_t *dst = (int32_t *)ctx->fpga_stats.p;
-        int rc = launch_fpga_stats(ctx, hc->dev, b->rs_n, b->rs_k, numFrames, (const uint8_t *)ctx->fpga_erased.p, dst + 16, dst);
-        if (rc) return rc;
-        LDPC_HIP_TRY(ctx, hipMemcpyAsync(host, dst, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+        LDPC_HIP_TRY(ctx, hipMemcpyAsync(host, ctx->fpga_stats.p, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
         LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
-    if (stats) { stats->num_LDPC_errors = host[0]; stats->num_RS_errors = host[1]; }
+    // error_type holds two ints (ldpc_erasure_decoder_top.cl:46-49); N_T = 2e8 frames x 8 RS blocks still fits
+    if (stats) { stats->num_LDPC_errors = (int)host[0]; stats->num_RS_errors = (int)host[1]; }
     if (data_out) {
         // the FPGA data_out never writes its buffer (ldpc_erasure_decoder_top.cl:140-150 is commented out);
         // the all-zero codeword is what a correct decode returns.

@@ -85,6 +85,7 @@ struct ldpc_amd_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipStream_t aux_in = nullptr, aux_out = nullptr;   // host-pointer pipeline: H2D / D2H streams (created on first use)
+    hipEvent_t pipe_events[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // ... and its events (created once)
     std::string err;
     std::vector<ldpc_amd::HostCode *> codes;
     std::vector<ldpc_amd::HostRs *> rs;
@@ -97,10 +98,16 @@ struct ldpc_amd_ctx {
     ldpc_amd::Scratch stage_in, stage_er, stage_out, stage_i32;  // host-pointer staging
     ldpc_amd::Scratch rsws;
     // FPGA-harness emulation state (ldpc_amd_data_in / _ldpc_erasure_decoder / _data_out)
+    // The run is streamed in chunks like the FPGA's frame loop (ldpc_erasure_decoder_perf_tests.cl:52): fpga_erased holds the
+    // flags of ONE chunk, fpga_stats the two running counters (+ per-frame results: of the whole run when it is short
+    // enough to keep them for ldpc_amd_fpga_frame_stats, else of one chunk).
     ldpc_amd::Scratch fpga_erased, fpga_stats;
-    long fpga_frames = 0;
+    long fpga_frames = -1;        // numFrames of the last ldpc_amd_data_in, -1 = none
+    long fpga_decoded = -1;       // numFrames the last decoder call ran over, -1 = no decoder call since data_in
+    bool fpga_kept = false;       // per-frame results of the whole run are in fpga_stats
     int fpga_code_ind = -1;
     int fpga_per64 = 0;
+    int fpga_seed = 0;
     int fpga_binary_code[4] = {-1, -1, -1, -1};
     int sm_count = 256;
     // profiling (ldpc_amd_set_profiling): event pairs per kernel kind
@@ -140,12 +147,12 @@ int launch_synth_erasures(ldpc_amd_ctx *ctx, uint64_t seed, uint32_t stream_id, 
                           uint64_t thresh, uint8_t *d);
 int launch_synth_bursty(ldpc_amd_ctx *ctx, uint64_t seed, int64_t first, int64_t count, double alpha, double beta,
                         double bias, uint8_t *d);
-int launch_synth_fpga(ldpc_amd_ctx *ctx, uint32_t seed, int64_t count, int per64, uint8_t *d);
+int launch_synth_fpga(ldpc_amd_ctx *ctx, uint32_t seed, uint64_t first, int64_t count, int per64, uint8_t *d);
 int launch_rs_decode(ldpc_amd_ctx *ctx, const HostRs &rs, int S, int64_t nblocks, const uint16_t *idx,
                      const uint8_t *val, uint8_t *msg);
 int launch_rs_encode(ldpc_amd_ctx *ctx, const HostRs &rs, int S, int64_t nblocks, const uint8_t *src, uint8_t *cw);
 int launch_fpga_stats(ldpc_amd_ctx *ctx, const DevCode &code, int rs_n, int rs_k, int64_t nframes,
-                      const uint8_t *erased0, const int32_t *residual_k, int32_t *stats /* [2] */);
+                      const uint8_t *erased0, const int32_t *residual_k, unsigned long long *stats /* [2], accumulated */);
 
 int scratch_reserve(ldpc_amd_ctx *ctx, Scratch &s, size_t bytes);
 // Brackets one kernel launch with events when profiling is on (no-ops otherwise).

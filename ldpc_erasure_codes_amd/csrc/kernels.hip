@@ -28,6 +28,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
+#include <set>
+#include <utility>
+#include <vector>
 
 #include "internal.h"
 #include "gf256_dev.h"
@@ -93,6 +97,7 @@ __device__ __forceinline__ void peel_wave(const EllT *ell_col, int mpad, uint16_
     nsteps = 0; sweeps = 0; maxlvl = 0;
     while (sweeps < max_sweeps) {               // :21  while (stopsig==0) && (itestep<itenum)
         sweeps++;                               // :23
+        const int solved_before = nsteps;
         for (int ch = 0; ch < nchunks && remaining > 0; ch++) {  // :27 (rows past the last erasure change nothing)
             const int row = (ch << 6) + lane;
             // two rounds of independent LDS reads: the check's neighbour ids, then their states
@@ -140,6 +145,9 @@ __device__ __forceinline__ void peel_wave(const EllT *ell_col, int mpad, uint16_
             wave_sync();
         }
         if (remaining == 0) break;              // :51-54
+        // a sweep that solved nothing leaves the state as it was: every further sweep repeats it, the reference runs
+        // them all and returns itestep = itenum -- same result without running them
+        if (nsteps == solved_before) { sweeps = max_sweeps; break; }
     }
 }
 
@@ -1128,10 +1136,12 @@ __global__ __launch_bounds__(256) void ge_write_kernel(GeParams p, const uint8_t
 
 // erasure flags of the FPGA source kernel: threefry4x32-20, key {1, seed}, counter = symbol index + 1
 // (OpenCL/device/ldpc_erasure_decoder_top.cl:74-75,96-110; rule restated in include/ldpc_erasure_amd_synth.h)
-__global__ void synth_fpga_kernel(uint32_t seed, uint64_t count, int per64, uint8_t *dst)
+// `first` = index of dst[0] in the run's symbol stream: a chunk of a long run continues the stream where the previous
+// chunk stopped (the counter is 32 bits wide in the reference and wraps after 2^32 symbols; ldpc_fpga_erased keeps that).
+__global__ void synth_fpga_kernel(uint32_t seed, uint64_t first, uint64_t count, int per64, uint8_t *dst)
 {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x)
-        dst[i] = (uint8_t)ldpc_fpga_erased(seed, i, per64);
+        dst[i] = (uint8_t)ldpc_fpga_erased(seed, first + i, per64);
 }
 
 // =================================================================================================
@@ -1171,13 +1181,30 @@ __global__ __launch_bounds__(1024) void copy_probe_kernel(const uint8_t *src, ui
 // =================================================================================================
 // Host side: constants, LDS layouts, launches
 // =================================================================================================
+// Every kernel instantiation that uses dynamic LDS is allowed the full 160 KB ONCE per device (process-wide kernel
+// attribute): a per-launch attribute sized for one code / S could be shrunk by another context between set and launch.
+static hipError_t allow_max_lds(const void *fn)
+{
+    static std::mutex mu;
+    static std::set<std::pair<int, const void *>> done;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({dev, fn})) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) done.insert({dev, fn});
+    return e;
+}
+
 hipError_t upload_constants(hipStream_t s)
 {
-    static uint32_t tab[256 * 8];
-    build_mul3_tables(tab);
+    // built once (magic static); uploads of concurrent ldpc_amd_init calls then all send the same bytes
+    static const std::vector<uint32_t> tab_v = [] { std::vector<uint32_t> t(256 * 8); build_mul3_tables(t.data()); return t; }();
+    const uint32_t *tab = tab_v.data();
     const GfHost &g = gf_host();
     hipError_t e;
-    if ((e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_mul3), tab, sizeof(tab), 0, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+    if ((e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_mul3), tab, 256 * 8 * sizeof(uint32_t), 0, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
     if ((e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_log), g.log, 256, 0, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
     if ((e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_exp), g.exp, 512, 0, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
     if ((e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_inv), g.inv, 256, 0, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
@@ -1218,8 +1245,7 @@ static hipError_t launch_peel_t(const PeelArgs &a, int wpb, hipStream_t s)
 #define LDPC_PEEL_CASE(D)                                                                                  \
     case D: {                                                                                              \
         auto kfn = ldpc_peel_kernel<D, FUSED, GT>;                                                         \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                           \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+        hipError_t e = allow_max_lds(reinterpret_cast<const void *>(kfn));                                 \
         if (e != hipSuccess) return e;                                                                     \
         hipLaunchKernelGGL(kfn, g, b, lds, s, a);                                                          \
         return hipGetLastError();                                                                          \
@@ -1315,8 +1341,7 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
 #define LDPC_SCATTER_T1(NTV, WPE, IPV)                                                                         \
     {                                                                                                        \
         auto kfn = ldpc_scatter_kernel<LPR, R, NTV, WPE, IPV>;                                                    \
-        LDPC_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                           \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, p.lds1));          \
+        LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(kfn)));                               \
         hipLaunchKernelGGL(kfn, grid, dim3(THREADS), (size_t)p.lds1, ctx->stream, sa);                       \
     }
     const bool ip = sa.inplace != 0;
@@ -1336,8 +1361,7 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
 #define LDPC_SCATTER_T2(NTV, IPV)                                                                            \
     {                                                                                                        \
         auto kfn = ldpc_scatter_big_kernel<LPR, R, NTV, IPV>;                                                     \
-        LDPC_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                           \
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, p.lds2));          \
+        LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(kfn)));                               \
         hipLaunchKernelGGL(kfn, g2, dim3(THREADS), (size_t)p.lds2, ctx->stream, sa);                         \
     }
         if (ip) { if (nt) LDPC_SCATTER_T2(true, true) else LDPC_SCATTER_T2(false, true) }
@@ -1532,7 +1556,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             if (v == 256 || v == 512 || v == 1024) ml_threads = v;
         }
         auto kfn = ldpc_ml_kernel;
-        LDPC_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, total));
+        LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(kfn)));
         hipEvent_t ev = prof_begin(ctx);
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(ml_threads), (size_t)total, ctx->stream, ma);
         LDPC_HIP_TRY(ctx, hipGetLastError());
@@ -1616,7 +1640,7 @@ int launch_rs_decode(ldpc_amd_ctx *ctx, const HostRs &rs, int S, int64_t nblocks
         a.ws = (uint8_t *)ctx->rsws.p;
     }
     auto kfn = rs_decode_kernel;
-    LDPC_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, off));
+    LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(kfn)));
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(threads), (size_t)off, ctx->stream, a);
     LDPC_HIP_TRY(ctx, hipGetLastError());
     return LDPC_AMD_OK;
@@ -1633,9 +1657,9 @@ int launch_rs_encode(ldpc_amd_ctx *ctx, const HostRs &rs, int S, int64_t nblocks
 }
 
 int launch_fpga_stats(ldpc_amd_ctx *ctx, const DevCode &code, int rs_n, int rs_k, int64_t nframes,
-                      const uint8_t *erased0, const int32_t *residual_sys, int32_t *stats)
+                      const uint8_t *erased0, const int32_t *residual_sys, unsigned long long *stats)
 {
-    LDPC_HIP_TRY(ctx, hipMemsetAsync(stats, 0, 2 * sizeof(int32_t), ctx->stream));
+    if (nframes <= 0) return LDPC_AMD_OK;
     const int grid = (int)std::min<int64_t>((nframes + 3) / 4, 4096);
     hipLaunchKernelGGL(fpga_stats_kernel, dim3(grid), dim3(256), 0, ctx->stream, code.n, rs_n, rs_k, nframes, erased0,
                        residual_sys, stats);
@@ -1656,7 +1680,7 @@ int launch_fpga_halves(ldpc_amd_ctx *ctx, const DevCode &code, int64_t nframes, 
 #define LDPC_FPGA_HALVES(D)                                                                                     \
     {                                                                                                          \
         auto kfn = fpga_halves_kernel<D>;                                                                      \
-        LDPC_HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(kfn))); \
         hipLaunchKernelGGL(kfn, grid, dim3(64 * wpb), lds, ctx->stream, code, nframes, erased, num_iter, residual_sys, iterations, wave0, wstride); \
     }
     if (code.degpad <= 8) LDPC_FPGA_HALVES(8)
@@ -1751,11 +1775,11 @@ int launch_synth_bursty(ldpc_amd_ctx *ctx, uint64_t seed, int64_t first, int64_t
     return LDPC_AMD_OK;
 }
 
-int launch_synth_fpga(ldpc_amd_ctx *ctx, uint32_t seed, int64_t count, int per64, uint8_t *d)
+int launch_synth_fpga(ldpc_amd_ctx *ctx, uint32_t seed, uint64_t first, int64_t count, int per64, uint8_t *d)
 {
     if (count <= 0) return LDPC_AMD_OK;
     const int grid = (int)std::min<int64_t>((count + 255) / 256, 16384);
-    hipLaunchKernelGGL(synth_fpga_kernel, dim3(grid), dim3(256), 0, ctx->stream, seed, (uint64_t)count, per64, d);
+    hipLaunchKernelGGL(synth_fpga_kernel, dim3(grid), dim3(256), 0, ctx->stream, seed, first, (uint64_t)count, per64, d);
     LDPC_HIP_TRY(ctx, hipGetLastError());
     return LDPC_AMD_OK;
 }

@@ -132,7 +132,14 @@ def test_cpp_host_harness_passes():
     r = subprocess.run([exe, "-h", "-c", "1", "-p", "9", "-n", "2000", "-i", "50"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert "PASSED" in r.stdout and "FAILED" not in r.stdout
-    assert "frame error rate" in r.stdout and "throughput in information bits/sec" in r.stdout
+    assert "frame error rate" in r.stdout and "frames/sec" in r.stdout and "bits/sec: " not in r.stdout
+    # the paper's N_T = 1e6 at PER 12/64 (Table I, tex:207: BLER 0.02, RS 7.3e-3) through the CLI: the run is streamed
+    r = subprocess.run([exe, "-h", "-c", "1", "-p", "12", "-n", "1000000", "-i", "50"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    line = [ln for ln in r.stdout.splitlines() if "frame error rate" in ln][0]
+    fer = float(line.split("frame error rate is:")[1].split(",")[0])
+    rs = float(line.split("RS FER=")[1])
+    assert 0.015 < fer < 0.025 and 0.0070 < rs < 0.0077, line
     r = subprocess.run([exe, "-e", "-c", "0"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "PASSED" in r.stdout
 
@@ -231,3 +238,81 @@ def test_two_contexts_from_two_threads(oracle, code_a):
         for f in (0, 17, 95):
             o_out, _, o_it, info, rc = oc.decode_packets(sym[f], era[f])
             assert sw[f] == o_it and res[f] == info[0] and np.array_equal(out[f], o_out)
+
+
+def test_first_library_use_is_two_concurrent_inits(tmp_path):
+    """A fresh process whose very first use of the library is two concurrent ldpc_amd_init calls (ctypes drops the GIL),
+    followed by decodes with different codes and packet sizes on the two handles: the GF tables are built once (magic
+    static), and the kernels' dynamic-LDS allowance is a once-only process-wide setting, not a per-launch one."""
+    script = tmp_path / "first_use.py"
+    script.write_text(
+        "import sys, threading\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import numpy as np\n"
+        "from ldpc_erasure_codes_amd import api, codes, synth\n"
+        "api.load_library()\n"
+        "go = threading.Barrier(2)\n"
+        "bad = []\n"
+        "def worker(code_ind, S, seed):\n"
+        "    go.wait()\n"
+        "    c = api.Context(0)\n"
+        "    try:\n"
+        "        c.selftest()\n"
+        "        code = codes.load_builtin(code_ind)\n"
+        "        h = c.load_builtin_code(code_ind, codes.DEFAULT_COEF_SEED[code_ind])\n"
+        "        src = synth.source(seed, 0, 48, code.k, S)\n"
+        "        src = src[:, :, 0] if S == 1 else src\n"
+        "        cw = c.encode(h, src)\n"
+        "        era = synth.erasures_uniform(seed + 1, 0, 48, code.n, 0.10)\n"
+        "        sym = cw.copy(); sym[era.astype(bool)] = 0\n"
+        "        for _ in range(6):\n"
+        "            out, sw, res, st = c.decode(h, sym, era)\n"
+        "            if not (np.array_equal(out, cw) and (st == 0).all()): bad.append((code_ind, S))\n"
+        "    except Exception as e:\n"
+        "        bad.append(repr(e))\n"
+        "    finally:\n"
+        "        c.close()\n"
+        "ts = [threading.Thread(target=worker, args=(1, 1024, 10)), threading.Thread(target=worker, args=(2, 64, 20))]\n"
+        "[t.start() for t in ts]; [t.join() for t in ts]\n"
+        "print('BAD' if bad else 'GOOD', bad)\n")
+    import sys
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "GOOD" in r.stdout, r.stdout + r.stderr
+
+
+def test_rs_decode_rejects_malformed_positions(ctx):
+    """recv_idx must be < n and strictly ascending (Matlab/ReedSolomonErasureCodes.m:80-81 builds it that way).  Host
+    pointers: LDPC_AMD_EINVAL.  Device pointers: the kernels check per block and decode the offending block to zeros
+    instead of indexing their tables with it; well-formed blocks of the same batch are unaffected."""
+    import torch
+    for (n, k, S) in ((255, 223, 1), (255, 192, 1), (255, 223, 16)):
+        rs = ctx.rs_create(n, k)
+        nb = 6
+        src = synth.source(900 + k, 0, nb, k, S)
+        src1 = src[:, :, 0] if S == 1 else src
+        cw = ctx.rs_encode(rs, n, k, src1)
+        rng = np.random.default_rng(5)
+        idx = np.stack([np.sort(rng.choice(n, k, replace=False)) for _ in range(nb)]).astype(np.uint16)
+        val = np.stack([cw[b][idx[b]] for b in range(nb)])
+        good = ctx.rs_decode(rs, idx, val)
+        assert np.array_equal(good, src1)
+        bad_idx = idx.copy()
+        bad_idx[1, 5] = n + 7                      # out of range
+        bad_idx[3, 10] = bad_idx[3, 9]             # duplicate (not strictly ascending)
+        bad_idx[4] = bad_idx[4][::-1]              # descending
+        with pytest.raises(api.LdpcAmdError):
+            ctx.rs_decode(rs, bad_idx, val)
+        L = api.load_library()
+        d_idx = torch.from_numpy(bad_idx.view(np.int16)).cuda()
+        d_val = torch.from_numpy(val).cuda()
+        d_msg = torch.full(val.shape, 0x77, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        rc = L.ldpc_amd_rs_decode_batch(ctx._h, rs, S, nb, d_idx.data_ptr(), d_val.data_ptr(), d_msg.data_ptr(), api.DEVICE_PTRS)
+        assert rc == 0
+        ctx.synchronize()
+        msg = d_msg.cpu().numpy()
+        for b in range(nb):
+            if b in (1, 3, 4):
+                assert not msg[b].any()
+            else:
+                assert np.array_equal(msg[b], src1[b])

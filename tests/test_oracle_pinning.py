@@ -371,3 +371,17 @@ def test_threefry4x32_20_known_answers(oracle):
     era = oracle.fpga_data_in_erasures(4242, 9, 50, 2040)
     assert np.array_equal(era, synth.fpga_erasures(4242, 9, 50, 2040))
     assert abs(era.mean() - 9 / 64) < 0.01
+
+
+def test_stat_helpers_two_sample_and_rounding():
+    """tests/stat_helpers.py (used by the Table I reproduction): sanity of the conditional two-sample test."""
+    from stat_helpers import consistent_with_rate, consistent_with_reported, two_sample_pvalue
+    assert two_sample_pvalue(0, 10**6, 0, 10**6) == 1.0
+    assert two_sample_pvalue(130, 10**6, 130, 10**6) > 0.9
+    assert two_sample_pvalue(130, 10**6, 400, 10**6) < 1e-10
+    assert consistent_with_reported(20400, 10**6, 0.015, 0.025, 10**6)[0]
+    assert not consistent_with_reported(74000, 10**6, 0.015, 0.025, 10**6)[0]
+    assert consistent_with_reported(3, 10**7, 0.0, 0.5e-6, 10**7)[0]
+    assert not consistent_with_reported(60, 10**7, 0.0, 0.5e-6, 10**7)[0]
+    assert consistent_with_rate(7223, 8 * 10**6, 9.028e-4)[0]
+    assert not consistent_with_rate(9000, 8 * 10**6, 9.028e-4)[0]
