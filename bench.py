@@ -1,23 +1,36 @@
 #!/usr/bin/env python3
-"""bench.py -- BASELINE.json's metric on BASELINE.json's configs[1]:
+"""bench.py -- BASELINE.json's metric, measured on one MI355X per process.
+
+Headline (`value`): BASELINE configs[1] = cfg 2:
 
     decoded frames/sec + recovered GB/s, n=2040 k=1530 GF(256) LDPC, 10 % uniform random erasures,
-    batch = 4096 frames per GPU, hybrid MP + ML decoder (max 10 sweeps, ML on).
+    batch = 4096 frames per GPU, hybrid MP + ML decoder (max 10 sweeps, ML armed).
 
-A "step" is one pass of the hot path (ldpc_amd_decode_batch: peel -> apply -> ML on residual frames) over
-one batch of synthetic frames that are already resident in HBM when the timed region starts.  Symbols are
-S-byte packets (--S, default 1024 = the reference's FPGA packet, OpenCL/host/src/main.cpp:42-47); the
-Matlab-exact scalar case S = 1 is measured in the same run and reported under "s1".
+A "step" is one pass of the hot path (ldpc_amd_decode_batch: peel -> packet kernel -> ML stage on the residual frames)
+over one batch of synthetic frames already resident in HBM when the timed region starts.  Symbols are S-byte packets
+(--S, default 1024 = the reference's FPGA packet, OpenCL/host/src/main.cpp:42-47); the Matlab-exact scalar case S = 1 is
+measured in the same run and reported under "s1".  At 10 % erasures the ML stage is armed but never triggers (the
+line says so: ml_trigger_rate); the configs that exercise it are in the "configs" block of the same JSON line:
+
+    cfg3  (2040,1530) hybrid MP+ML, Gilbert-Elliott erasures pushed until the ML stage triggers on >= 10 % of the frames
+          (SURVEY.md 8d), S = 1024 and S = 1
+    cfg4  (4080,3060) [synthesised matrix] vs 16 x RS(255,223) on the same erasure patterns, 65536 frames, S = 1
+    cfg5  mixed (4000,2000) + (2040,1530) stream, 1:1, 10 % -- at N = 1 one GPU's share (8192 frames) of the 8-GPU job
+
+each with frames/s, per-kernel ms (HIP events inside the library, on the launch stream), algorithmic bytes,
+the roofline fraction they give, ML-trigger / rank-deficient rates and a bounded CPU-baseline sample of the same inputs.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    ... bench.py --gpus 8 --config 5 --gather outputs      # BASELINE configs[4] on an 8-GPU node (strong scaling)
 
-One process per GPU; frames are sharded with no data-path collective (weak scaling: 4096 frames per GPU);
-RCCL is used once, for the final gather of the per-frame status words.  Rank 0 prints ONE JSON line.
+One process per GPU; frames are sharded with no data-path collective (cfg 2: weak scaling, 4096 frames per GPU; cfg 5:
+the 65536-frame mixed stream split over the ranks); RCCL is used once, for the final gather (status words, or outputs +
+status words with --gather outputs).  Rank 0 prints ONE JSON line.
 
-The oracle (oracle/) is used here only (a) to time the CPU baseline and (b) to spot-check a few decoded
-frames after the timed region; the measured path is the HIP library behind the C ABI.
+The oracle (oracle/) is used here only (a) to time the CPU baseline and (b) to spot-check decoded frames after the timed
+region; the measured path is the HIP library behind the C ABI.
 """
 import argparse
 import json
@@ -31,33 +44,18 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-N_CODE, K_CODE, CODE_IND = 2040, 1530, 1
-PER = 0.10
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 SEED_SRC, SEED_ERA = 20261004, 20261005
+GE_PARAMS = (0.13, 0.8, 10.0)   # cfg 3: alpha, beta, good_transition_bias -- ML stage on ~28 % of the frames
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "round2_pmc_summary.json")
 
-
-SCATTER_KERNEL = "ldpc_scatter_kernel<16, 2, true, 8, false>"  # LPR=16 (256-byte row pieces), 2 pieces in flight, nt, 8 waves/SIMD, out of place
-PEEL_S1_KERNEL = "ldpc_peel_kernel<14, true, false>"  # 14 neighbours per check, fused S = 1 apply, code tables in LDS
-
-
-def pmc_traffic(kernel, frames, S):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE /
-    WRITE_SIZE passes of this same command, gfx950 correction applied: tools/summarize_profiles.py).  The counters
-    cannot be read from inside this process, so the value is the one measured for the default batch
-    (4096 frames, S = 1024 / 1); None when there is no summary or the shape differs."""
-    path = os.path.join(ROOT, "profiles", "round1_pmc_summary.json")
-    if frames != 4096 or S not in (1, 1024) or not os.path.exists(path):
-        return None
-    try:
-        ks = json.load(open(path))["kernels"]
-        k = ks.get(kernel) or next(v for name, v in ks.items() if name.startswith(kernel.split("<")[0] + "<")
-                                   and (S == 1) == ("peel" in name and name.split(",")[1].strip().startswith("true")))
-    except (KeyError, ValueError, StopIteration):
-        return None
-    if S == 1:  # the S = 1 launches are the large ones of that kernel in the profiled run
-        return 2.0 * k["FETCH_SIZE_KB_max"] * 1024.0 + k["WRITE_SIZE_KB_max"] * 1024.0
-    return k["traffic_bytes"]
+# BASELINE.json configs -> (code_ind, channel, frames)
+WORKLOADS = {
+    "cfg2": dict(code=1, channel=("uniform", 0.10), frames=4096),
+    "cfg3": dict(code=1, channel=("bursty",) + GE_PARAMS, frames=4096),
+    "cfg4": dict(code=3, channel=("uniform", 0.10), frames=65536, rs=(255, 223)),
+    "cfg5": dict(codes=(2, 1), channel=("uniform", 0.10), frames=65536),
+}
 
 
 def alg_bytes_per_frame(n, S):
@@ -65,50 +63,147 @@ def alg_bytes_per_frame(n, S):
     return 2 * n * S + n + 8
 
 
+def rs_alg_bytes_per_block(k, S):
+    # k*S in + 2k (indices) + k*S out
+    return 2 * k * S + 2 * k
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE / WRITE_SIZE
+    passes of this same command, gfx950 correction applied: tools/summarize_profiles.py).  The counters cannot be read from
+    inside this process; a launch plan the summary does not know gets a warning, not a silent null."""
+    if not os.path.exists(PMC_SUMMARY):
+        print(f"bench.py: no PMC summary at {PMC_SUMMARY}: roofline.traffic = null", file=sys.stderr)
+        return None
+    try:
+        ks = json.load(open(PMC_SUMMARY))["kernels"]
+    except (KeyError, ValueError):
+        print(f"bench.py: {PMC_SUMMARY} is not a PMC summary: roofline.traffic = null", file=sys.stderr)
+        return None
+    if kernel not in ks:
+        print(f"bench.py: PMC summary has no entry for the launched kernel '{kernel}' (has: {sorted(ks)}): "
+              "roofline.traffic = null -- re-run the --pmc passes for this launch plan", file=sys.stderr)
+        return None
+    return ks[kernel].get("traffic_bytes")
+
+
 # ----------------------------------------------------------------------------------------------------
-# CPU baseline ("port": the oracle's lane-vectorised restatement of the Matlab decoder), run BEFORE the
-# GPU is touched so that forked workers never inherit a HIP context.
+# CPU baseline ("port": oracle/oracle.c, the line-faithful restatement of the Matlab decoders), run BEFORE the GPU is
+# touched so that forked workers never inherit a HIP context.  Every worker decodes frames of the SAME batch the GPU
+# decodes (same seeds, same frame indices; worker w takes frames w, w + W, ...) for a bounded time.
 # ----------------------------------------------------------------------------------------------------
+def host_erasures(cfg, code_ind, n, nframes, frame0=0):
+    from oracle import oracle_py
+    ch = WORKLOADS[cfg]["channel"]
+    if ch[0] == "uniform":
+        return oracle_py.synth_erasures_uniform(SEED_ERA + code_ind, frame0, nframes, n, ch[1])
+    return oracle_py.synth_erasures_bursty(SEED_ERA + code_ind, frame0, nframes, n, ch[1], ch[2], ch[3])
+
+
 def _cpu_worker(args):
-    wid, S, nframes, chunk = args
+    wid, nworkers, cfg, S, seconds = args
     from ldpc_erasure_codes_amd import codes, synth
     from oracle import oracle_py
-    code = codes.load_builtin(CODE_IND)
-    oc = oracle_py.OracleCode(code)
-    busy = 0.0
-    done = 0
-    frame0 = 1_000_000 + wid * nframes  # frames disjoint from the GPU batch, same generator
-    while done < nframes:
-        c = min(chunk, nframes - done)
-        src = synth.source(SEED_SRC, frame0 + done, c, code.k, S)
-        era = synth.erasures_uniform(SEED_ERA, frame0 + done, c, code.n, PER)
-        if S == 1:
-            cw = np.stack([oc.encode(src[f, :, 0]) for f in range(c)])
-            t0 = time.perf_counter()
-            out, sw, res, st = oc.decode_batch_s1(cw, era)
-            busy += time.perf_counter() - t0
-            assert np.array_equal(out, cw)
-        else:
-            cws = [oc.encode(src[f]) for f in range(c)]
-            t0 = time.perf_counter()
-            outs = [oc.decode_packets(cws[f], era[f]) for f in range(c)]
-            busy += time.perf_counter() - t0
-            assert all(np.array_equal(outs[f][0], cws[f]) for f in range(c))
-        done += c
-    return done, busy
+    w = WORKLOADS[cfg]
+    code_inds = w.get("codes", (w.get("code"),))
+    F = w["frames"]
+    ocs, eras = {}, {}
+    for ci in code_inds:
+        c = codes.load_builtin(ci)
+        ocs[ci] = (c, oracle_py.OracleCode(c))
+        if cfg == "cfg3":
+            eras[ci] = host_erasures(cfg, ci, c.n, F)   # the GE chain is sequential: the whole batch, once
+    rs_g = oracle_py.rs_generator(*w["rs"]) if "rs" in w else None
+    busy = busy_rs = 0.0
+    frames = blocks = ml = 0
+    f = wid
+    chunk = 64 if S == 1 else 2
+    while f < F and busy + busy_rs < seconds:
+        ids = list(range(f, min(F, f + chunk * nworkers), nworkers))
+        f = ids[-1] + nworkers
+        for ci in code_inds:
+            c, oc = ocs[ci]
+            mine = [g for g in ids if len(code_inds) == 1 or (g % len(code_inds)) == code_inds.index(ci)]
+            if not mine:
+                continue
+            if cfg == "cfg3":
+                era = eras[ci][mine]
+            else:
+                era = np.concatenate([host_erasures(cfg, ci, c.n, 1, g) for g in mine])
+            keep = era.sum(axis=1) < c.m       # Matlab harness: decoder called only if num_erasures < n-k (...Sim.m:216)
+            era = np.ascontiguousarray(era[keep])
+            mine = [g for g, kp in zip(mine, keep) if kp]
+            if not mine:
+                continue
+            src = np.concatenate([oracle_py.synth_source(SEED_SRC + ci, g, 1, c.k, S) for g in mine])
+            if S == 1:
+                cw = np.stack([oc.encode(src[i, :, 0]) for i in range(len(mine))])
+                t0 = time.perf_counter()
+                out, sw, res, st = oc.decode_batch_s1(cw, era)
+                busy += time.perf_counter() - t0
+                okf = st <= 1
+                assert np.array_equal(out[okf], cw[okf])
+                ml += int((res > 0).sum())
+            else:
+                cws = [oc.encode(src[i]) for i in range(len(mine))]
+                t0 = time.perf_counter()
+                outs = [oc.decode_packets(cws[i], era[i]) for i in range(len(mine))]
+                busy += time.perf_counter() - t0
+                ml += sum(int(o[3][0] > 0) for o in outs)
+            frames += len(mine)
+            if rs_g is not None:
+                rn, rk = w["rs"]
+                for i in range(len(mine)):
+                    for b in range(c.n // rn):
+                        recv = np.nonzero(era[i, b * rn:(b + 1) * rn] == 0)[0]
+                        if recv.size < rk:
+                            continue      # RS decode attempted only for blocks with >= k received (SURVEY 8d cfg 4)
+                        idx = recv[:rk].astype(np.uint16)
+                        rsrc = oracle_py.synth_source(SEED_SRC + 77, mine[i] * 16 + b, 1, rk, 1)[0, :, 0]
+                        rcw = oracle_py.rs_encode(rs_g, rsrc)
+                        t0 = time.perf_counter()
+                        msg, _ = oracle_py.rs_decode(rs_g, idx, np.ascontiguousarray(rcw[idx]))
+                        busy_rs += time.perf_counter() - t0
+                        assert np.array_equal(msg, rsrc)
+                        blocks += 1
+    return frames, busy, blocks, busy_rs, ml
 
 
-def cpu_baseline(S, cores, frames_per_core):
-    chunk = 256 if S == 1 else 8
-    t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(w, S, frames_per_core, chunk) for w in range(cores)])
-    wall = time.perf_counter() - t0
-    rate = sum(d / b for d, b in res)  # workers run concurrently: aggregate = sum of per-worker rates
-    return {"value": rate, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{sum(d for d, _ in res)} frames of the same workload (S={S}) decoded by oracle/oracle.c, "
-                      f"{frames_per_core} per core on {cores} cores, decode time only ({wall:.1f} s wall incl. input generation)",
-            "per_core": rate / cores}
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, S, seconds):
+    """single_thread (one worker) and all_cores (one worker per core of this process's affinity mask)."""
+    cores_total = len(os.sched_getaffinity(0))
+    out = {"unit": "frames/s", "kind": "port", "cores_total": cores_total, "cpu_model": cpu_model()}
+    for label, nw in (("single_thread", 1), ("all_cores", min(cores_total, 256))):
+        t0 = time.perf_counter()
+        with mp.get_context("fork").Pool(nw) as pool:
+            res = pool.map(_cpu_worker, [(w, nw, cfg, S, seconds if nw > 1 else 0.5 * seconds) for w in range(nw)])
+        wall = time.perf_counter() - t0
+        rate = sum(fr / b for fr, b, _, _, _ in res if b > 0)   # workers run concurrently: aggregate = sum of rates
+        out[label] = rate
+        frames = sum(r[0] for r in res)
+        if label == "all_cores":
+            out.update({"value": rate, "cores": nw,
+                        "sample": f"{frames} frames of the GPU's own batch ({cfg}, S={S}) decoded by oracle/oracle.c, "
+                                  f"~{seconds:g} s of decode time per worker on {nw} workers ({wall:.1f} s wall incl. input "
+                                  f"generation and encoding); single_thread = the same with one worker",
+                        "ml_frames_in_sample": sum(r[4] for r in res)})
+            blocks = sum(r[2] for r in res)
+            if blocks:
+                out["rs_blocks_per_s"] = sum(bl / b for _, _, bl, b, _ in res if b > 0)
+                out["rs_blocks_in_sample"] = blocks
+        elif sum(r[2] for r in res):
+            out["rs_blocks_per_s_single_thread"] = sum(bl / b for _, _, bl, b, _ in res if b > 0)
+    return out
 
 
 def cpu_cfg1(reps=200):
@@ -116,7 +211,7 @@ def cpu_cfg1(reps=200):
     (Matlab/My_LDPC_Erasure_Decoder.m, 50 sweeps max), FPGA data_in erasures at PER 9/64 -- the oracle on one core."""
     from ldpc_erasure_codes_amd import codes, synth
     from oracle import oracle_py
-    code = codes.load_builtin(CODE_IND, 0)  # coefficient seed 0 = the binary code (all ones)
+    code = codes.load_builtin(1, 0)  # coefficient seed 0 = the binary code (all ones)
     oc = oracle_py.OracleCode(code)
     era = synth.fpga_erasures(1, 9, reps, code.n)
     busy, ok, sweeps = 0.0, 0, 0
@@ -133,134 +228,346 @@ def cpu_cfg1(reps=200):
 
 
 # ----------------------------------------------------------------------------------------------------
-def run_gpu(args, rank, world, local_rank):
-    import torch
-    import torch.distributed as dist
-    from ldpc_erasure_codes_amd import api, codes, sharding
+# GPU side
+# ----------------------------------------------------------------------------------------------------
+class Gpu:
+    def __init__(self, args, rank, world, local_rank):
+        import torch
+        import torch.distributed as dist
+        from ldpc_erasure_codes_amd import api
+        self.torch, self.dist = torch, dist
+        self.args, self.rank, self.world = args, rank, world
+        # LDPC_BENCH_BACKEND=gloo is only for rehearsing the N > 1 launch path on a box with fewer GPUs than ranks
+        self.backend = os.environ.get("LDPC_BENCH_BACKEND", "nccl")
+        if self.backend == "gloo":
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        if world > 1:
+            if self.backend == "gloo":
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=self.dev)
+        self.ctx = api.Context(local_rank)
+        self.ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # torch events and our kernels share one stream
+        self.ctx.selftest()
+        self.handles = {}
 
-    # LDPC_BENCH_BACKEND=gloo is only for rehearsing the N > 1 launch path on a box with fewer GPUs than ranks
-    backend = os.environ.get("LDPC_BENCH_BACKEND", "nccl")
-    if backend == "gloo":
-        local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        if backend == "gloo":
-            dist.init_process_group("gloo")
+    def close(self):
+        self.ctx.close()
+        if self.world > 1:
+            self.dist.destroy_process_group()
+
+    def code(self, code_ind):
+        from ldpc_erasure_codes_amd import codes
+        if code_ind not in self.handles:
+            h = self.ctx.load_builtin_code(code_ind, codes.DEFAULT_COEF_SEED[code_ind])
+            self.handles[code_ind] = (h,) + tuple(self.ctx.code_info(h)[:2])
+        return self.handles[code_ind]
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def make_batch(self, cfg, code_ind, S, frame_ids=None, frame0=0, nframes=None):
+        """Codewords, received symbols and erasure flags, generated and encoded on the device.  frame_ids: explicit global
+        frame indices (mixed stream); else frames [frame0, frame0 + nframes)."""
+        torch, ctx = self.torch, self.ctx
+        h, n, k = self.code(code_ind)
+        ch = WORKLOADS[cfg]["channel"]
+        if frame_ids is not None:
+            # frames of a mixed stream are not contiguous in the per-frame generators' index space: generate the covering
+            # range and pick (cheap: S = 1)
+            lo, hi = (int(frame_ids.min()), int(frame_ids.max()) + 1) if len(frame_ids) else (0, 0)
+            sel = torch.from_numpy(np.asarray(frame_ids) - lo).to(self.dev)
+            frame0, nframes = lo, hi - lo
+        F = nframes
+        src = torch.empty((F, k, S), dtype=torch.uint8, device=self.dev)
+        ctx.synth_source(SEED_SRC + code_ind, frame0, F, k, S, src)
+        era = torch.empty((F, n), dtype=torch.uint8, device=self.dev)
+        if ch[0] == "uniform":
+            ctx.synth_erasures_uniform(SEED_ERA + code_ind, frame0, F, n, ch[1], era)
         else:
-            dist.init_process_group("nccl", device_id=dev)
-
-    ctx = api.Context(local_rank)
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)  # torch events and our kernels share one stream
-    ctx.selftest()
-    h = ctx.load_builtin_code(CODE_IND, codes.DEFAULT_COEF_SEED[CODE_IND])
-    n, k, _ = ctx.code_info(h)
-    F = args.frames
-    frame0 = rank * F  # every rank decodes its own, different frames
-
-    def make_batch(S):
-        src = torch.empty((F, k, S), dtype=torch.uint8, device=dev)
-        ctx.synth_source(SEED_SRC, frame0, F, k, S, src)
-        cw = ctx.encode(h, src if S > 1 else src.reshape(F, k))
+            ctx.synth_erasures_bursty(SEED_ERA + code_ind, frame0, F, n, ch[1], ch[2], ch[3], era)
+        if frame_ids is not None:
+            src, era = src[sel].contiguous(), era[sel].contiguous()
+        keep = era.sum(dim=1, dtype=torch.int32) < (n - k)   # harness guard: decoder called only if E0 < n-k (...Sim.m:216)
+        if not bool(keep.all()):
+            src, era = src[keep].contiguous(), era[keep].contiguous()
+        cw = ctx.encode(h, src if S > 1 else src.reshape(src.shape[0], k))
         del src
-        era = torch.empty((F, n), dtype=torch.uint8, device=dev)
-        ctx.synth_erasures_uniform(SEED_ERA, frame0, F, n, PER, era)
         sym = cw.clone()
         sym[era.bool()] = 0x5A  # the payload of an erased symbol is garbage, never the true value
-        return cw, sym, era
+        return cw, sym, era, keep
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def measure(S, steps, warmup):
-        cw, sym, era = make_batch(S)
+    def time_decode(self, h, sym, era, steps, warmup, after_steps=None):
+        """W untimed + K timed decode steps bracketed by barrier + synchronize; per-kernel HIP-event times from the library."""
+        torch, ctx = self.torch, self.ctx
+        F = sym.shape[0]
         out = torch.empty_like(sym)
-        sw = torch.empty(F, dtype=torch.int32, device=dev)
-        res = torch.empty(F, dtype=torch.int32, device=dev)
-        st = torch.empty(F, dtype=torch.int32, device=dev)
-        counts = [F] * world
+        sw = torch.empty(F, dtype=torch.int32, device=self.dev)
+        res = torch.empty(F, dtype=torch.int32, device=self.dev)
+        st = torch.empty(F, dtype=torch.int32, device=self.dev)
         for _ in range(warmup):
             ctx.decode(h, sym, era, out=out, sweeps=sw, residual=res, status=st)
         ctx.get_profile()
         ctx.set_profiling(True)
-        barrier()
+        self.barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             ctx.decode(h, sym, era, out=out, sweeps=sw, residual=res, status=st)
-        # the one collective of the job: final gather of the status words (12 B/frame) over RCCL/xGMI
-        parts = sharding.gather_status(torch.stack([sw, res, st]), counts)
-        barrier()
+        extra = after_steps(out, sw, res, st) if after_steps else None
+        self.barrier()
         dt = time.perf_counter() - t0
         ctx.set_profiling(False)
         prof = ctx.get_profile()
-        dt = sharding.max_over_ranks(dt, dev)
-        assert len(parts) == world
-        # correctness of what was just timed: every frame of cfg 2 decodes to its codeword
-        ok = bool(torch.equal(out, cw)) and int(st.max()) == 0
-        hist = torch.bincount(sw, minlength=12).cpu().numpy().tolist()
-        ml_rate = float((res > 0).float().mean())
-        sample = (sym[:2].cpu().numpy(), era[:2].cpu().numpy(), out[:2].cpu().numpy(), sw[:2].cpu().numpy())
-        inplace = None
-        copy_gbps = None
-        if S >= 16:
-            # the copy rate this box reaches (same buffers, same streaming loads/stores), quoted next to
-            # the nominal HBM peak; bytes moved = read + write
-            nb = sym.numel()
-            copy_ms = ctx.copy_probe(sym, out, reps=5)
-            copy_gbps = 2.0 * nb / (copy_ms * 1e-3) / 1e9
-        if S >= 16 and world == 1:
-            # extension, reported separately and never as `value`: LDPC_AMD_INPLACE decodes inside the caller's frame
-            # buffer and writes only the erased symbols (the reference always returns a copy)
-            buf = sym.clone()
-            for _ in range(2):
-                ctx.decode(h, buf, era, sweeps=sw, residual=res, status=st, inplace=True)
-            ctx.get_profile()
-            ctx.set_profiling(True)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(steps):
-                ctx.decode(h, buf, era, sweeps=sw, residual=res, status=st, inplace=True)
-            torch.cuda.synchronize()
-            dti = time.perf_counter() - t1
-            ctx.set_profiling(False)
-            pi = ctx.get_profile()
-            inplace = {"ms_per_step": dti / steps * 1e3, "frames_per_s": F * steps / dti, "verified": bool(torch.equal(buf, cw)),
-                       "kernel_ms": {kk: (v[0] / max(v[1], 1)) for kk, v in pi.items()}}
-            del buf
-        del cw, sym, era, out
-        torch.cuda.empty_cache()
-        return dt, prof, ok, hist, ml_rate, sample, inplace, copy_gbps
+        names = ctx.profile_kernel_names()
+        return dict(dt=dt, out=out, sw=sw, res=res, st=st, extra=extra, names=names,
+                    kernel_ms={kk: (v[0] / max(v[1], 1)) for kk, v in prof.items()})
 
+
+def summarize(g, r, cw, n, k, S, steps, frames_all_ranks):
+    """Common numbers of one timed decode run."""
+    torch = g.torch
+    F = cw.shape[0]
+    ok_frames = r["st"] <= 1
+    verified = bool(torch.equal(r["out"][ok_frames], cw[ok_frames]))
+    resid = r["res"][r["res"] > 0].float()
+    ms = r["dt"] / steps * 1e3
+    ab = alg_bytes_per_frame(n, S) * F
+    return {
+        "frames": F, "frames_per_s": frames_all_ranks * steps / r["dt"], "ms_per_step": ms, "steps": steps,
+        "recovered_GBps": frames_all_ranks * steps / r["dt"] * k * S / 1e9,
+        "kernel_ms": r["kernel_ms"], "kernels": r["names"],
+        "alg_bytes_per_step": ab, "roofline_frac": ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "sweeps_hist": torch.bincount(r["sw"], minlength=12).cpu().numpy().tolist(),
+        "ml_trigger_rate": float((r["res"] > 0).float().mean()) if F else 0.0,
+        "rank_deficient_rate": float((r["st"] == 2).float().mean()) if F else 0.0,
+        "undecoded_rate": float((r["st"] >= 2).float().mean()) if F else 0.0,
+        "mean_residual": float(resid.mean()) if resid.numel() else 0.0,
+        "max_residual": int(resid.max()) if resid.numel() else 0,
+        "verified": verified,
+    }
+
+
+def pick_samples(r, sym, era, want_ml):
+    """A few frames of the timed output for the oracle spot check (after the timed region): the first two, plus -- when the
+    ML stage ran -- the first frame it solved and the first rank-deficient one."""
+    ids = [0, 1]
+    if want_ml:
+        for code in (1, 2):
+            hit = (r["st"] == code).nonzero().flatten()
+            if hit.numel():
+                ids.append(int(hit[0]))
+    ids = sorted(set(i for i in ids if i < sym.shape[0]))
+    take = lambda t: t[ids].cpu().numpy()   # noqa: E731
+    return ids, take(sym), take(era), take(r["out"]), take(r["sw"]), take(r["st"])
+
+
+def oracle_check(code_ind, S, sample):
+    from ldpc_erasure_codes_amd import codes
+    from oracle import oracle_py
+    oc = oracle_py.OracleCode(codes.load_builtin(code_ind))
+    ids, sym, era, out, sw, st = sample
+    ok = True
+    for i in range(len(ids)):
+        if S == 1:
+            o, osw, _, ost = oc.decode_batch_s1(sym[i:i + 1], era[i:i + 1])
+            ok = ok and bool(np.array_equal(o[0], out[i])) and int(osw[0]) == int(sw[i]) and int(ost[0]) == int(st[i])
+        else:
+            o, _, it, info, _ = oc.decode_packets(sym[i], era[i])
+            ok = ok and bool(np.array_equal(o, out[i])) and it == int(sw[i])
+    return ok, len(ids)
+
+
+def run_cfg2(g, args):
+    """Headline.  Returns {S: result}."""
+    torch = g.torch
+    from ldpc_erasure_codes_amd import sharding
+    h, n, k = g.code(1)
+    F = args.frames
     result = {}
     for S in ([args.S, 1] if args.S != 1 else [1]):
         steps = args.steps if S == args.S else max(args.steps, 20)
-        dt, prof, ok, hist, ml_rate, sample, inplace, copy_gbps = measure(S, steps, args.warmup)
-        fps = world * F * steps / dt
+        cw, sym, era, _ = g.make_batch("cfg2", 1, S, frame0=g.rank * F, nframes=F)   # every rank its own frames
+        counts = [F] * g.world
+        # the one collective of the job: final gather of the status words (12 B/frame) over RCCL/xGMI
+        r = g.time_decode(h, sym, era, steps, args.warmup,
+                          after_steps=lambda out, sw, res, st: sharding.gather_status(torch.stack([sw, res, st]), counts))
+        r["dt"] = sharding.max_over_ranks(r["dt"], g.dev)
+        assert len(r["extra"]) == g.world
+        s = summarize(g, r, cw, n, k, S, steps, g.world * F)
+        s["verified"] = s["verified"] and int(r["st"].max()) == 0   # every frame of cfg 2 decodes to its codeword
+        s["sample"] = pick_samples(r, sym, era, False)
         kind = "apply" if S > 1 else "peel"
-        kms, kcnt = prof[kind]
-        kavg = kms / max(kcnt, 1)  # ms per launch of the dominant kernel, HIP events on its own stream
+        kavg = r["kernel_ms"][kind]  # ms per launch of the dominant kernel, HIP events on its own stream
         ab = alg_bytes_per_frame(n, S) * F
         ach = ab / (kavg * 1e-3) / 1e9 if kavg > 0 else 0.0
-        result[S] = {
-            "value": fps, "ms_per_step": dt / steps * 1e3, "recovered_GBps": fps * k * S / 1e9, "steps": steps,
-            "verified": ok, "sweeps_hist": hist, "ml_trigger_rate": ml_rate,
-            "kernel_ms": {kk: (v[0] / max(v[1], 1)) for kk, v in prof.items()},
-            "roofline": {"bound": "hbm", "kernel": SCATTER_KERNEL if S > 1 else PEEL_S1_KERNEL,
-                         "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                         "traffic": pmc_traffic(SCATTER_KERNEL if S > 1 else PEEL_S1_KERNEL, F, S),
-                         "alg_bytes_per_launch": ab, "avg_launch_ms": kavg,
-                         "copy_kernel_GBps": copy_gbps,
-                         "frac_of_copy": (ach / copy_gbps) if copy_gbps else None},
-            "sample": sample, "inplace": inplace,
-        }
-    ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
+        copy_gbps = None
+        if S >= 16:
+            # SURVEY.md 8(d): the copy rate this box reaches (same buffers, same streaming loads/stores), quoted next to the
+            # nominal HBM peak; bytes moved = read + write
+            copy_ms = g.ctx.copy_probe(sym, r["out"], reps=5)
+            copy_gbps = 2.0 * sym.numel() / (copy_ms * 1e-3) / 1e9
+        s["roofline"] = {"bound": "hbm", "kernel": r["names"][kind], "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBPS, "traffic": pmc_traffic(r["names"][kind]) if F == 4096 else None,
+                         "alg_bytes_per_launch": ab, "avg_launch_ms": kavg, "copy_kernel_GBps": copy_gbps,
+                         "frac_of_copy": (ach / copy_gbps) if copy_gbps else None}
+        s["inplace"] = None
+        if S >= 16 and g.world == 1:
+            # extension, reported separately and never as `value`: LDPC_AMD_INPLACE decodes inside the caller's frame buffer
+            # and writes only the erased symbols (the reference always returns a copy)
+            buf = sym.clone()
+            sw, res, st = r["sw"], r["res"], r["st"]
+            for _ in range(2):
+                g.ctx.decode(h, buf, era, sweeps=sw, residual=res, status=st, inplace=True)
+            g.ctx.get_profile()
+            g.ctx.set_profiling(True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                g.ctx.decode(h, buf, era, sweeps=sw, residual=res, status=st, inplace=True)
+            torch.cuda.synchronize()
+            dti = time.perf_counter() - t1
+            g.ctx.set_profiling(False)
+            pi = g.ctx.get_profile()
+            s["inplace"] = {"ms_per_step": dti / steps * 1e3, "frames_per_s": F * steps / dti, "verified": bool(torch.equal(buf, cw)),
+                            "kernel_ms": {kk: (v[0] / max(v[1], 1)) for kk, v in pi.items()}}
+            del buf
+        result[S] = s
+        del cw, sym, era, r
+        torch.cuda.empty_cache()
     return result, n, k
 
 
+def run_cfg3(g, args, S):
+    torch = g.torch
+    h, n, k = g.code(1)
+    cw, sym, era, keep = g.make_batch("cfg3", 1, S, frame0=0, nframes=WORKLOADS["cfg3"]["frames"])
+    steps = max(3, min(args.steps, 10))
+    r = g.time_decode(h, sym, era, steps, min(args.warmup, 2))
+    s = summarize(g, r, cw, n, k, S, steps, cw.shape[0])
+    s["workload"] = (f"BASELINE cfg3: (2040,1530) hybrid MP+ML, Gilbert-Elliott alpha={GE_PARAMS[0]} beta={GE_PARAMS[1]} "
+                     f"bias={GE_PARAMS[2]:g} (chain carried across frames), {WORKLOADS['cfg3']['frames']} frames drawn, "
+                     f"{cw.shape[0]} with E0 < n-k decoded (the rest skipped as in ErasureCodes_NonBinaryLDPCSim.m:216), S={S}")
+    s["frames_skipped_E0_ge_m"] = int((~keep).sum())
+    s["sample"] = pick_samples(r, sym, era, True)
+    del cw, sym, era, r
+    torch.cuda.empty_cache()
+    return s
+
+
+def run_cfg4(g, args):
+    """(4080,3060) LDPC next to 16 x RS(255,223) over the same 4080-symbol erasure patterns (block i = symbols
+    255 i ... 255 i + 254, ErasureCodes_NonBinaryLDPCSim.m:210-214), S = 1."""
+    torch, ctx = g.torch, g.ctx
+    from ldpc_erasure_codes_amd import codes
+    if not codes.have_builtin(3):
+        return None
+    h, n, k = g.code(3)
+    F = WORKLOADS["cfg4"]["frames"]
+    cw, sym, era, _ = g.make_batch("cfg4", 3, 1, frame0=0, nframes=F)
+    steps = 3
+    r = g.time_decode(h, sym, era, steps, 1)
+    s = summarize(g, r, cw, n, k, 1, steps, F)
+    s["workload"] = ("BASELINE cfg4: (4080,3060) GF(256) LDPC [matrix synthesised by tools/hgen.cpp -- the reference names the "
+                     "code but does not ship it] vs 16 x RS(255,223) on the same erasure patterns, 65536 frames, uniform 10 %, S=1")
+    s["sample"] = pick_samples(r, sym, era, False)
+    rn, rk = WORKLOADS["cfg4"]["rs"]
+    rs = ctx.rs_create(rn, rk)
+    blocks = era.reshape(F * (n // rn), rn)
+    received = blocks == 0
+    can = received.sum(dim=1) >= rk                       # RS decode attempted only for blocks with >= k received
+    order = torch.argsort((~received).to(torch.uint8), dim=1, stable=True)[:, :rk]   # first k received positions, ascending
+    sel = torch.nonzero(can).flatten()
+    B = int(sel.numel())
+    rsrc = torch.empty((B, rk), dtype=torch.uint8, device=g.dev)
+    ctx.synth_source(SEED_SRC + 77, 0, B, rk, 1, rsrc)
+    rcw = ctx.rs_encode(rs, rn, rk, rsrc)
+    idx = order[sel].to(torch.int16).contiguous()
+    val = torch.gather(rcw, 1, order[sel]).contiguous()
+    msg = ctx.rs_decode(rs, idx, val)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        msg = ctx.rs_decode(rs, idx, val)
+    ev1.record()
+    torch.cuda.synchronize()
+    trs = (time.perf_counter() - t0) / steps
+    rs_ab = rs_alg_bytes_per_block(rk, 1) * B
+    s_rs = {"blocks_total": F * (n // rn), "blocks_decodable": B, "blocks_per_s": B / trs, "ms_per_step": trs * 1e3,
+            "kernel_ms": {"rs_decode": ev0.elapsed_time(ev1) / steps}, "frame_equivalents_per_s": B / (n // rn) / trs,
+            "alg_bytes_per_step": rs_ab, "roofline_frac": rs_ab / trs / 1e9 / HBM_PEAK_GBPS,
+            "verified": bool(torch.equal(msg, rsrc)),
+            "block_failure_rate": 1.0 - B / float(F * (n // rn))}
+    del cw, sym, era, r, rcw, idx, val, order, msg
+    torch.cuda.empty_cache()
+    return {"ldpc": s, "rs": s_rs}
+
+
+def run_cfg5(g, args, total, gather):
+    """Mixed (4000,2000) + (2040,1530) stream, 1:1, sharded over the ranks: bucket by code, each rank decodes its block of
+    every bucket, then ONE gather (status words, or outputs + status words).  Decode and gather are timed separately."""
+    torch = g.torch
+    from ldpc_erasure_codes_amd import sharding
+    ids = sharding.mixed_stream_ids(total)
+    handles = {ci: g.code(ci) for ci in WORKLOADS["cfg5"]["codes"]}
+    mine = sharding.shard_mixed(ids, g.rank, g.world)
+    batches = {}
+    for ci, gidx in mine.items():
+        cw, sym, era, keep = g.make_batch("cfg5", ci, 1, frame_ids=gidx)
+        assert bool(keep.all())
+        F = sym.shape[0]
+        batches[ci] = dict(cw=cw, sym=sym, era=era, out=torch.empty_like(sym),
+                           sw=torch.empty(F, dtype=torch.int32, device=g.dev), res=torch.empty(F, dtype=torch.int32, device=g.dev),
+                           st=torch.empty(F, dtype=torch.int32, device=g.dev))
+
+    def decode_all():
+        for ci, b in batches.items():
+            g.ctx.decode(handles[ci][0], b["sym"], b["era"], out=b["out"], sweeps=b["sw"], residual=b["res"], status=b["st"])
+
+    steps = max(3, min(args.steps, 10))
+    for _ in range(min(args.warmup, 2)):
+        decode_all()
+    g.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        decode_all()
+    g.barrier()
+    t1 = time.perf_counter()
+    shard = {ci: {"gidx": mine[ci], "out": b["out"], "words": torch.stack([b["sw"], b["res"], b["st"]])} for ci, b in batches.items()}
+    full = sharding.gather_mixed(ids, shard, g.world, gather)
+    g.barrier()
+    t2 = time.perf_counter()
+    dt_dec = sharding.max_over_ranks(t1 - t0, g.dev)
+    dt_gat = sharding.max_over_ranks(t2 - t1, g.dev)
+    ok = all(bool(torch.equal(b["out"], b["cw"])) and int(b["st"].max()) == 0 for b in batches.values() if b["sym"].shape[0])
+    gathered_frames = sum(int(v["words"].shape[1]) for v in full.values())
+    gbytes = sum(int(v["words"].numel()) * 4 + (int(v["out"].numel()) if v["out"] is not None else 0) for v in full.values())
+    ab = sum(alg_bytes_per_frame(handles[ci][1], 1) * int((ids == ci).sum()) for ci in handles)
+    per_step = (dt_dec / steps) + dt_gat          # one job = decode the stream once + the final gather
+    s = {"workload": f"BASELINE cfg5: mixed (4000,2000) + (2040,1530) stream 1:1, uniform 10 %, {total} frames over {g.world} "
+                     f"GPU(s) (bucketed by code, contiguous blocks per rank), S=1, final gather of {gather}",
+         "frames": total, "frames_this_rank": sum(b["sym"].shape[0] for b in batches.values()),
+         "frames_per_s": total / per_step, "decode_ms_per_step": dt_dec / steps * 1e3, "gather_ms": dt_gat * 1e3,
+         "gather": gather, "gathered_frames": gathered_frames, "gathered_bytes_per_rank": gbytes,
+         "gather_GBps_per_rank": gbytes / dt_gat / 1e9 if dt_gat > 0 else None,
+         "alg_bytes_per_step": ab, "roofline_frac": ab / (dt_dec / steps) / 1e9 / HBM_PEAK_GBPS / g.world,
+         "steps": steps, "verified": ok and gathered_frames == total}
+    b0 = batches[WORKLOADS["cfg5"]["codes"][0]]
+    s["samples"] = {}
+    for ci, b in batches.items():
+        if b["sym"].shape[0] >= 2:
+            r = dict(out=b["out"], sw=b["sw"], st=b["st"])
+            s["samples"][ci] = pick_samples(r, b["sym"], b["era"], False)
+    del b0
+    return s
+
+
+# ----------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -268,8 +575,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step (BASELINE cfg 2: 4096)")
     ap.add_argument("--S", type=int, default=1024, help="bytes per symbol (1 = Matlab model, 1024 = FPGA packet)")
-    ap.add_argument("--cpu-frames", type=int, default=None, help="CPU-baseline frames per core (default: sized for ~10 s)")
+    ap.add_argument("--config", default="2", choices=["2", "3", "4", "5"],
+                    help="2 (default): headline cfg 2 + the 'configs' block with cfg 3/4/5 at N = 1; 3/4/5: that config alone "
+                         "(5 = the 65536-frame mixed stream sharded over --gpus ranks)")
+    ap.add_argument("--gather", default="status", choices=["status", "outputs"], help="cfg 5: what the final gather moves")
+    ap.add_argument("--total-frames", type=int, default=None, help="cfg 5: frames of the whole stream (default 65536)")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="CPU-baseline decode time per worker and leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="headline only (skip the cfg 3/4/5 block)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -279,70 +592,136 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
+    want_block = args.config == "2" and world == 1 and not args.no_configs
+    do_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
 
+    # ---- CPU legs first (forked workers must not inherit a HIP context)
     cpu = {}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cores = max(1, min(len(os.sched_getaffinity(0)), 16))
-        # ~3 ms/frame/core at S=1024 and ~0.2 ms at S=1 on a current x86 core -> about 10 s of CPU work per core
-        cpu[args.S] = cpu_baseline(args.S, cores, args.cpu_frames or (1024 if args.S > 1 else 65536))
-        if args.S != 1:
-            cpu[1] = cpu_baseline(1, cores, args.cpu_frames or 65536)
-        cpu["cfg1"] = cpu_cfg1()
+    if do_cpu:
+        T = args.cpu_seconds
+        if args.config == "2":
+            cpu[("cfg2", args.S)] = cpu_baseline("cfg2", args.S, T)
+            if args.S != 1:
+                cpu[("cfg2", 1)] = cpu_baseline("cfg2", 1, T)
+            cpu["cfg1"] = cpu_cfg1()
+        if want_block or args.config == "3":
+            cpu[("cfg3", 1024)] = cpu_baseline("cfg3", 1024, T)
+            cpu[("cfg3", 1)] = cpu_baseline("cfg3", 1, T)
+        if want_block or args.config == "4":
+            cpu[("cfg4", 1)] = cpu_baseline("cfg4", 1, T)
+        if want_block or args.config == "5":
+            cpu[("cfg5", 1)] = cpu_baseline("cfg5", 1, T)
 
-    result, n, k = run_gpu(args, rank, world, local_rank)
+    g = Gpu(args, rank, world, local_rank)
+    line = None
+    checks = []   # (where, code_ind, S, sample) -> oracle spot checks after the timed regions
+    if args.config == "2":
+        result, n, k = run_cfg2(g, args)
+        block = {}
+        if want_block:
+            for S in (1024, 1):
+                block[f"cfg3_S{S}"] = run_cfg3(g, args, S)
+            c4 = run_cfg4(g, args)
+            if c4:
+                block["cfg4"] = c4
+            block["cfg5"] = run_cfg5(g, args, WORKLOADS["cfg5"]["frames"] // 8, args.gather)
+            block["cfg5"]["workload"] += " -- ONE GPU's share (1/8) of the 8-GPU job; `--config 5 --gpus 8` runs the whole stream"
+    elif args.config == "3":
+        block = {f"cfg3_S{S}": run_cfg3(g, args, S) for S in sorted({args.S, 1}, reverse=True)}
+    elif args.config == "4":
+        block = {"cfg4": run_cfg4(g, args)}
+    else:
+        block = {"cfg5": run_cfg5(g, args, args.total_frames or WORKLOADS["cfg5"]["frames"], args.gather)}
+    g.close()
     if rank != 0:
         return
 
-    # spot-check of the timed output against the oracle (after the timed region)
-    from ldpc_erasure_codes_amd import codes
-    from oracle import oracle_py
-    oc = oracle_py.OracleCode(codes.load_builtin(CODE_IND))
-    for S, r in result.items():
-        sym, era, out, sw = r.pop("sample")
-        for f in range(sym.shape[0]):
-            if S == 1:
-                o, osw, _, _ = oc.decode_batch_s1(sym[f:f + 1], era[f:f + 1])
-                r["verified"] = r["verified"] and bool(np.array_equal(o[0], out[f])) and int(osw[0]) == int(sw[f])
-            else:
-                o, _, it, _, _ = oc.decode_packets(sym[f], era[f])
-                r["verified"] = r["verified"] and bool(np.array_equal(o, out[f])) and it == int(sw[f])
+    # ---- oracle spot checks of what was just timed (after the timed regions)
+    def check(entry, code_ind, S):
+        if entry is None or "sample" not in entry:
+            return
+        ok, cnt = oracle_check(code_ind, S, entry.pop("sample"))
+        entry["verified"] = bool(entry["verified"] and ok)
+        entry["oracle_spot_check_frames"] = cnt
 
-    main_r = result[args.S]
-    line = {
-        "metric": "decoded frames/sec (+ recovered GB/s), n=2040 k=1530 GF(256) LDPC hybrid MP+ML erasure decode",
-        "value": main_r["value"], "unit": "frames/s", "recovered_GBps": main_r["recovered_GBps"],
-        "n_gpus": world, "steps": main_r["steps"], "warmup": args.warmup, "ms_per_step": main_r["ms_per_step"],
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"BASELINE cfg2: n=2040,k=1530 GF(256) LDPC (H_nb seed {2040}), 10% uniform random erasures, "
-                               f"batch={args.frames} frames per GPU, S={args.S} bytes/symbol, max_sweeps=10, ML on",
-                   "frames_per_gpu": args.frames, "S": args.S, "per": PER, "code": "n2040_k1530",
-                   "sharding": f"{world} x {args.frames} independent frames, status gather over RCCL"},
-        "verified_bit_exact": main_r["verified"], "sweeps_hist": main_r["sweeps_hist"],
-        "ml_trigger_rate": main_r["ml_trigger_rate"], "kernel_ms": main_r["kernel_ms"],
-        "roofline": main_r["roofline"],
-    }
-    if main_r.get("inplace"):
-        ip = main_r["inplace"]
-        ach_ip = alg_bytes_per_frame(n, args.S) * args.frames / (ip["kernel_ms"]["apply"] * 1e-3) / 1e9
-        line["inplace_extension"] = {
-            "note": "LDPC_AMD_INPLACE (out == sym, only erased symbols written; the reference always returns a copy). Reported "
-                    "against the same algorithmic bytes as SURVEY.md 8(d) prescribes; not the headline value.",
-            "frames_per_s": ip["frames_per_s"], "ms_per_step": ip["ms_per_step"], "verified_bit_exact": ip["verified"],
-            "kernel_ms": ip["kernel_ms"], "roofline_frac_vs_algorithmic_bytes": ach_ip / HBM_PEAK_GBPS}
-    if args.S in cpu:
-        line["cpu_baseline"] = cpu[args.S]
-        line["gpu_over_cpu"] = main_r["value"] / cpu[args.S]["value"]
-    if "cfg1" in cpu:
-        line["cfg1_cpu_reference_row"] = cpu["cfg1"]
-    if 1 in result and args.S != 1:
-        s1 = result[1]
-        line["s1"] = {"note": "same batch with S=1 (one GF(256) element per symbol: the Matlab model, bit-exact incl. iterations); "
-                              "latency/LDS-bound by construction, HBM fraction reported for completeness",
-                      "value": s1["value"], "unit": "frames/s", "ms_per_step": s1["ms_per_step"], "steps": s1["steps"],
-                      "verified_bit_exact": s1["verified"], "roofline": s1["roofline"]}
-        if 1 in cpu:
-            line["s1"]["cpu_baseline"] = cpu[1]
-            line["s1"]["gpu_over_cpu"] = s1["value"] / cpu[1]["value"]
+    if args.config == "2":
+        for S, r in result.items():
+            check(r, 1, S)
+    for name, e in block.items():
+        if name.startswith("cfg3"):
+            check(e, 1, int(name.split("_S")[1]))
+            key = ("cfg3", int(name.split("_S")[1]))
+        elif name == "cfg4" and e:
+            check(e["ldpc"], 3, 1)
+            key = ("cfg4", 1)
+        elif name == "cfg5":
+            for ci, smp in e.pop("samples").items():
+                ok, cnt = oracle_check(ci, 1, smp)
+                e["verified"] = bool(e["verified"] and ok)
+            key = ("cfg5", 1)
+        else:
+            continue
+        if key in cpu:
+            cb = cpu[key]
+            tgt = e["ldpc"] if name == "cfg4" else e
+            tgt["cpu_baseline"] = cb
+            if name != "cfg5" or world == 1:
+                tgt["gpu_over_cpu_all_cores"] = tgt["frames_per_s"] / cb["value"] if cb.get("value") else None
+            if name == "cfg4" and cb.get("rs_blocks_per_s"):
+                e["rs"]["gpu_over_cpu_all_cores"] = e["rs"]["blocks_per_s"] / cb["rs_blocks_per_s"]
+
+    if args.config == "2":
+        main_r = result[args.S]
+        line = {
+            "metric": "decoded frames/sec (+ recovered GB/s), n=2040 k=1530 GF(256) LDPC hybrid MP+ML erasure decode "
+                      "(cfg 2: MP path, ML stage armed but not triggered at 10 % erasures; cfg 3 in 'configs' exercises it)",
+            "value": main_r["frames_per_s"], "unit": "frames/s", "recovered_GBps": main_r["recovered_GBps"],
+            "n_gpus": world, "steps": main_r["steps"], "warmup": args.warmup, "ms_per_step": main_r["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"BASELINE cfg2: n=2040,k=1530 GF(256) LDPC (H_nb seed {2040}), 10% uniform random erasures, "
+                                   f"batch={args.frames} frames per GPU, S={args.S} bytes/symbol, max_sweeps=10, ML on",
+                       "frames_per_gpu": args.frames, "S": args.S, "per": 0.10, "code": "n2040_k1530",
+                       "sharding": f"{world} x {args.frames} independent frames, status gather over RCCL"},
+            "verified_bit_exact": main_r["verified"], "sweeps_hist": main_r["sweeps_hist"],
+            "ml_trigger_rate": main_r["ml_trigger_rate"], "kernel_ms": main_r["kernel_ms"],
+            "roofline": main_r["roofline"],
+        }
+        if main_r.get("inplace"):
+            ip = main_r["inplace"]
+            ach_ip = alg_bytes_per_frame(n, args.S) * args.frames / (ip["kernel_ms"]["apply"] * 1e-3) / 1e9
+            line["inplace_extension"] = {
+                "note": "LDPC_AMD_INPLACE (out == sym, only erased symbols written; the reference always returns a copy). Reported "
+                        "against the same algorithmic bytes as SURVEY.md 8(d) prescribes; not the headline value.",
+                "frames_per_s": ip["frames_per_s"], "ms_per_step": ip["ms_per_step"], "verified_bit_exact": ip["verified"],
+                "kernel_ms": ip["kernel_ms"], "roofline_frac_vs_algorithmic_bytes": ach_ip / HBM_PEAK_GBPS}
+        if ("cfg2", args.S) in cpu:
+            line["cpu_baseline"] = cpu[("cfg2", args.S)]
+            line["gpu_over_cpu"] = main_r["frames_per_s"] / cpu[("cfg2", args.S)]["value"]
+        if "cfg1" in cpu:
+            line["cfg1_cpu_reference_row"] = cpu["cfg1"]
+        if 1 in result and args.S != 1:
+            s1 = result[1]
+            line["s1"] = {"note": "same batch with S=1 (one GF(256) element per symbol: the Matlab model, bit-exact incl. iterations); "
+                                  "latency/LDS-bound by construction, HBM fraction reported for completeness",
+                          "value": s1["frames_per_s"], "unit": "frames/s", "ms_per_step": s1["ms_per_step"], "steps": s1["steps"],
+                          "verified_bit_exact": s1["verified"], "roofline": s1["roofline"]}
+            if ("cfg2", 1) in cpu:
+                line["s1"]["cpu_baseline"] = cpu[("cfg2", 1)]
+                line["s1"]["gpu_over_cpu"] = s1["frames_per_s"] / cpu[("cfg2", 1)]["value"]
+        if block:
+            line["configs"] = block
+    else:
+        first = next(iter(block.values()))
+        head = first["ldpc"] if args.config == "4" else first
+        line = {
+            "metric": f"decoded frames/sec, BASELINE cfg{args.config}", "value": head["frames_per_s"], "unit": "frames/s",
+            "n_gpus": world, "steps": head["steps"], "warmup": args.warmup,
+            "ms_per_step": head.get("ms_per_step", head.get("decode_ms_per_step")), "higher_is_better": True,
+            "scaling": "strong" if args.config == "5" else "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": head["workload"]}, "verified_bit_exact": head["verified"], "configs": block,
+        }
+        if head.get("cpu_baseline"):
+            line["cpu_baseline"] = head["cpu_baseline"]
     print(json.dumps(line))
 
 

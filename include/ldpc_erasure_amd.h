@@ -194,6 +194,10 @@ int ldpc_amd_data_out(ldpc_amd_ctx *ctx, ldpc_amd_symbol_type *data_out, int cod
 #define LDPC_AMD_PROF_KINDS 3
 int ldpc_amd_set_profiling(ldpc_amd_ctx *ctx, int enable);
 int ldpc_amd_get_profile(ldpc_amd_ctx *ctx, double ms[LDPC_AMD_PROF_KINDS], int64_t launches[LDPC_AMD_PROF_KINDS]);
+/* Name (as rocprofv3 prints it, e.g. "ldpc_scatter_kernel<16, 2, true, 8, false>") of the kernel instantiation the LAST
+ * launch of that kind used -- the launch plan depends on code, S and batch, so a report must not hard-code it.
+ * "" when no kernel of the kind was launched yet. */
+const char *ldpc_amd_profile_kernel_name(ldpc_amd_ctx *ctx, int kind);
 
 /* ---- diagnostics ----------------------------------------------------------------------------------- */
 /* Device self-test of the GF(256) primitives (packed multiply vs. table) -> 0 when all 65536 products and

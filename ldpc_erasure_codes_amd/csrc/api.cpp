@@ -956,6 +956,12 @@ int ldpc_amd_get_profile(ldpc_amd_ctx *ctx, double ms[LDPC_AMD_PROF_KINDS], int6
     return LDPC_AMD_OK;
 }
 
+const char *ldpc_amd_profile_kernel_name(ldpc_amd_ctx *ctx, int kind)
+{
+    if (!ctx || kind < 0 || kind >= LDPC_AMD_PROF_KINDS) return "";
+    return ctx->prof_names[kind].c_str();
+}
+
 // ---- diagnostics ---------------------------------------------------------------------------------------
 int ldpc_amd_selftest(ldpc_amd_ctx *ctx)
 {

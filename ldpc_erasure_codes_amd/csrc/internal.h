@@ -114,6 +114,7 @@ struct ldpc_amd_ctx {
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[LDPC_AMD_PROF_KINDS];
     std::vector<hipEvent_t> prof_pool;
+    std::string prof_names[LDPC_AMD_PROF_KINDS];   // template instantiation the last launch of each kind used
 };
 
 namespace ldpc_amd {

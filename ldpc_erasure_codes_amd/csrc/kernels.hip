@@ -1345,6 +1345,12 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
         hipLaunchKernelGGL(kfn, grid, dim3(THREADS), (size_t)p.lds1, ctx->stream, sa);                       \
     }
     const bool ip = sa.inplace != 0;
+    {
+        char nm[96];
+        snprintf(nm, sizeof(nm), "ldpc_scatter_kernel<%d, %d, %s, %d, %s>", LPR, R, nt ? "true" : "false", p.two_tier ? 8 : 4,
+                 ip ? "true" : "false");
+        ctx->prof_names[LDPC_AMD_PROF_APPLY] = nm;
+    }
     if (p.two_tier) {
         if (ip) { if (nt) LDPC_SCATTER_T1(true, 8, true) else LDPC_SCATTER_T1(false, 8, true) }
         else { if (nt) LDPC_SCATTER_T1(true, 8, false) else LDPC_SCATTER_T1(false, 8, false) }
@@ -1476,6 +1482,11 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         LDPC_HIP_TRY(ctx, launch_peel_t<false>(pa, wpb, ctx->stream));
         return LDPC_AMD_OK;
     }
+    {
+        char nm[96];
+        snprintf(nm, sizeof(nm), "ldpc_peel_kernel<%d, %s, %s>", cd.degpad, fused ? "true" : "false", gt ? "true" : "false");
+        ctx->prof_names[LDPC_AMD_PROF_PEEL] = nm;
+    }
     if (fused) {
         hipEvent_t ev = prof_begin(ctx);
         if (gt) { LDPC_HIP_TRY(ctx, (launch_peel_t<true, true>(pa, wpb, ctx->stream))); }
@@ -1510,6 +1521,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         aa.code = cd; aa.S = d.S; aa.nframes = nf; aa.sym = d.sym; aa.erased = d.erased; aa.in_rows = d.in_rows; aa.out = d.out;
         aa.sched_hdr = pa.sched_hdr; aa.sched_steps = pa.sched_steps; aa.sched_lvlend = pa.sched_lvlend;
         const size_t lds = (size_t)cd.m * 4 + (size_t)(cd.m + 2) * 2;
+        ctx->prof_names[LDPC_AMD_PROF_APPLY] = "ldpc_apply_kernel";
         ev = prof_begin(ctx);
         hipLaunchKernelGGL(ldpc_apply_kernel, dim3((unsigned)nf), dim3(512), lds, ctx->stream, aa);
         LDPC_HIP_TRY(ctx, hipGetLastError());
@@ -1557,6 +1569,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         }
         auto kfn = ldpc_ml_kernel;
         LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(kfn)));
+        ctx->prof_names[LDPC_AMD_PROF_ML] = "ldpc_ml_kernel";
         hipEvent_t ev = prof_begin(ctx);
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(ml_threads), (size_t)total, ctx->stream, ma);
         LDPC_HIP_TRY(ctx, hipGetLastError());
