@@ -375,7 +375,7 @@ void ldpc_amd_cleanup(ldpc_amd_ctx *ctx)
         if (r->d_pt) (void)hipFree(r->d_pt);
         delete r;
     }
-    Scratch *all[] = {&ctx->sched, &ctx->mlws, &ctx->mlstate, &ctx->mllist, &ctx->biglist, &ctx->stage_in, &ctx->stage_er,
+    Scratch *all[] = {&ctx->sched, &ctx->mlws, &ctx->mlstate, &ctx->mlops, &ctx->mlrec, &ctx->mllist, &ctx->biglist, &ctx->stage_in, &ctx->stage_er,
                       &ctx->stage_out, &ctx->stage_i32, &ctx->rsws, &ctx->fpga_erased, &ctx->fpga_stats};
     for (Scratch *s : all) scratch_free(*s);
     for (auto &v : ctx->prof_events)

@@ -93,6 +93,8 @@ struct ldpc_amd_ctx {
     ldpc_amd::Scratch sched;    // per-frame schedules (packet path)
     ldpc_amd::Scratch mlws;     // ML stage matrices
     ldpc_amd::Scratch mlstate;  // residual erasure masks of the frames handed to the ML stage
+    ldpc_amd::Scratch mlops;    // packets: arena of the ML stage's solve schedules
+    ldpc_amd::Scratch mlrec;    // packets: [ML-list slot][8] u32 schedule records
     ldpc_amd::Scratch mllist;   // [1 + nframes] int32: count, frame ids
     ldpc_amd::Scratch biglist;  // [1 + nframes] int32: frames with many steps (scatter tier 2)
     ldpc_amd::Scratch stage_in, stage_er, stage_out, stage_i32;  // host-pointer staging

@@ -61,7 +61,7 @@ __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgc
 // Diagnostic build only (-DLDPC_AMD_STAMPS, tools/stamp_peel.py): per-phase cycle sums of the peel kernel go to a
 // buffer nothing else reads.  The product build contains no stamp.
 #ifdef LDPC_AMD_STAMPS
-__device__ unsigned long long g_peel_stamps[16];
+__device__ unsigned long long g_peel_stamps[32];   // [0..15] peel / packet kernel, [16..31] ML kernel
 #define LDPC_STAMP(i)                                                                     \
     do {                                                                                  \
         const unsigned long long t__ = __builtin_amdgcn_s_memtime();                      \
@@ -1364,8 +1364,14 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
         sa.tcap = sa.code.m; sa.nslots = sa.code.m; sa.big_list = big_list;
         scatter_set_lds(sa, p, sa.code.m);
         const dim3 g2((unsigned)std::min<int64_t>(sa.nframes * sa.nslices, ctx->sm_count));
+        const char *env_r2 = getenv("LDPC_AMD_SCATTER_R2");   // rows in flight per lane group in tier 2 (128-VGPR budget)
+        const bool r2_4 = LPR == 16 && env_r2 && atoi(env_r2) == 4;
 #define LDPC_SCATTER_T2(NTV, IPV)                                                                            \
-    {                                                                                                        \
+    if (r2_4) {                                                                                              \
+        auto kfn = ldpc_scatter_big_kernel<LPR, (LPR == 16 ? 4 : R), NTV, IPV>;                                   \
+        LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(kfn)));                               \
+        hipLaunchKernelGGL(kfn, g2, dim3(THREADS), (size_t)p.lds2, ctx->stream, sa);                         \
+    } else {                                                                                                 \
         auto kfn = ldpc_scatter_big_kernel<LPR, R, NTV, IPV>;                                                     \
         LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(kfn)));                               \
         hipLaunchKernelGGL(kfn, g2, dim3(THREADS), (size_t)p.lds2, ctx->stream, sa);                         \
@@ -1551,6 +1557,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         ma.lds_lg = off; off += 256;
         ma.lds_ex = off; off += 1024;
         ma.lds_misc = off; off += 128;
+        ma.lds_lvl = off; off += align_up(4 * (cd.m + 2), 16);
         ma.lds_A = off;
         if (off > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "ML stage: LDS need %d bytes", off);
         ma.capA = (kLdsMax - off) & ~15;
@@ -1558,10 +1565,33 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         int grid = (int)std::min<int64_t>(nf, (int64_t)ctx->sm_count);
         const size_t perA = (size_t)cd.m * maxrow, perR = fused ? 0 : (size_t)cd.m * d.S;
         if ((rc = scratch_reserve(ctx, ctx->mlws, (perA + perR) * grid + 256))) return rc;
-        ma.work = (int32_t *)ctx->mlws.p;                 // first 256 bytes: the frame hand-out counter
-        ma.wsA = (uint8_t *)ctx->mlws.p + 256;
+        ma.work = (int32_t *)ctx->mlws.p;                 // first 256 bytes: [0] frame hand-out counter, [2..3] arena bump
+        ma.wsA = (uint8_t *)ctx->mlws.p + 256;            // pointer (u64), [4] task counter of the solve kernel
         ma.wsR = ma.wsA + perA * grid;
-        LDPC_HIP_TRY(ctx, hipMemsetAsync(ma.work, 0, sizeof(int32_t), ctx->stream));
+        LDPC_HIP_TRY(ctx, hipMemsetAsync(ma.work, 0, 32, ctx->stream));
+        // packets: the ML kernel factors every residual system on bytes and emits a solve schedule (64-bit ops grouped by
+        // dependency level) into an arena; ldpc_ml_solve_kernel then runs the schedules on LDS-resident row slices.
+        // Frames whose schedule does not fit the arena are solved inside the ML kernel (same bytes, slower).
+        const char *env_sv = getenv("LDPC_AMD_ML_SOLVE");
+        ma.use_solve = (!fused && !(env_sv && atoi(env_sv) == 0)) ? 1 : 0;
+        int solve_b = 0;
+        if (ma.use_solve) {
+            solve_b = 128;
+            while (solve_b > 16 && (d.S % solve_b) != 0) solve_b >>= 1;
+            const int tail_sv = align_up(4 * (2 * cd.m + 6), 16) + 8192 + 64;
+            while (solve_b > 16 && cd.m * solve_b + tail_sv > 79 * 1024) solve_b >>= 1;
+            if (cd.m * solve_b + tail_sv > kLdsMax || cd.n > 65535) ma.use_solve = 0;
+        }
+        if (ma.use_solve) {
+            const size_t words = std::min<size_t>(std::max<size_t>((size_t)nf * 8192, (size_t)1 << 21), (size_t)1 << 27);   // 64 KB per frame; 16 MB ... 1 GB
+            if ((rc = scratch_reserve(ctx, ctx->mlops, words * 8)) || (rc = scratch_reserve(ctx, ctx->mlrec, (size_t)nf * 32))) return rc;
+            ma.ops = (unsigned long long *)ctx->mlops.p; ma.ops_cap = words;
+            ma.ops_head = (unsigned long long *)(ma.work + 2);
+            ma.rec = (uint32_t *)ctx->mlrec.p;
+        } else if (!fused) {
+            if ((rc = scratch_reserve(ctx, ctx->mlrec, (size_t)nf * 32))) return rc;
+            ma.rec = (uint32_t *)ctx->mlrec.p;   // the fall-back flag is written in either case
+        }
         int ml_threads = 1024;
         if (const char *e = getenv("LDPC_AMD_ML_THREADS")) {
             const int v = atoi(e);
@@ -1573,6 +1603,31 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         hipEvent_t ev = prof_begin(ctx);
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(ml_threads), (size_t)total, ctx->stream, ma);
         LDPC_HIP_TRY(ctx, hipGetLastError());
+        if (ma.use_solve && !(env_sv && atoi(env_sv) == 2)) {   // =2: diagnostic, schedules emitted but not run (timing of the factor part)
+            MlSolveArgs sv{};
+            sv.code = cd; sv.S = d.S; sv.nslices = d.S / solve_b; sv.ml_list = ma.ml_list; sv.rec = ma.rec; sv.ops = ma.ops;
+            sv.out = d.out; sv.work = ma.work + 4;
+            int o = cd.m * solve_b;
+            sv.lds_tab = o; o += align_up(4 * (2 * cd.m + 6), 16);
+            sv.lds_mt = o; o += 8192;
+            sv.lds_misc = o; o += 64;
+            const int per_cu = std::max(1, std::min(2, kLdsMax / o));
+            const dim3 sg((unsigned)std::min<int64_t>(nf * sv.nslices, (int64_t)ctx->sm_count * per_cu));
+#define LDPC_ML_SOLVE(LPRV)                                                                                   \
+    {                                                                                                        \
+        auto sfn = ldpc_ml_solve_kernel<LPRV>;                                                               \
+        LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(sfn)));                               \
+        hipLaunchKernelGGL(sfn, sg, dim3(512), (size_t)o, ctx->stream, sv);                                  \
+    }
+            switch (solve_b) {
+                case 128: LDPC_ML_SOLVE(8) break;
+                case 64: LDPC_ML_SOLVE(4) break;
+                case 32: LDPC_ML_SOLVE(2) break;
+                default: LDPC_ML_SOLVE(1) break;
+            }
+#undef LDPC_ML_SOLVE
+            LDPC_HIP_TRY(ctx, hipGetLastError());
+        }
         prof_end(ctx, LDPC_AMD_PROF_ML, ev);
     }
     return LDPC_AMD_OK;
@@ -1706,12 +1761,12 @@ int launch_fpga_halves(ldpc_amd_ctx *ctx, const DevCode &code, int64_t nframes, 
 }
 
 #ifdef LDPC_AMD_STAMPS
-extern "C" int ldpc_amd_debug_peel_stamps(ldpc_amd_ctx *ctx, unsigned long long *out16, int reset)
+extern "C" int ldpc_amd_debug_peel_stamps(ldpc_amd_ctx *ctx, unsigned long long *out32, int reset)
 {
     LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    LDPC_HIP_TRY(ctx, hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_peel_stamps), 16 * sizeof(unsigned long long)));
+    LDPC_HIP_TRY(ctx, hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_peel_stamps), 32 * sizeof(unsigned long long)));
     if (reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[32] = {0};
         LDPC_HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_peel_stamps), z, sizeof(z)));
     }
     return LDPC_AMD_OK;

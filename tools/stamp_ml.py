@@ -11,8 +11,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-PHASES = {8: "build", 9: "barrier wait", 10: "step header", 11: "row updates", 12: "packet rhs updates", 13: "next-column scan",
-          14: "back substitution", 15: "write-back"}
+PHASES = {16: "build", 17: "barrier wait", 18: "step header", 19: "row updates", 20: "next-column scan",
+          21: "packets: backward levels (one wavefront)", 22: "packets: schedule count pass", 23: "packets: schedule place pass",
+          24: "fall-back: forward level sort", 25: "fall-back: forward pull", 26: "fall-back: backward levels + sort",
+          27: "back substitution / fall-back backward pull", 28: "write-back"}
 
 
 def main():
@@ -34,7 +36,7 @@ def main():
     era_np = np.ascontiguousarray(era_np[era_np.sum(axis=1) < n - k])
     F = era_np.shape[0]
     era = torch.from_numpy(era_np).to(dev)
-    for S in (1, 1024):
+    for S in ([int(x) for x in sys.argv[1:]] or [1, 1024]):
         src_t = torch.empty((F, k, S), dtype=torch.uint8, device=dev)
         ctx.synth_source(11, 0, F, k, S, src_t)
         cw = ctx.encode(h, src_t if S > 1 else src_t.reshape(F, k)).reshape(F, n, S)
@@ -43,7 +45,7 @@ def main():
         ctx.synchronize()
         rs_c = rs.cpu().numpy()
         order = np.argsort(rs_c)
-        buf = (C.c_ulonglong * 16)()
+        buf = (C.c_ulonglong * 32)()
         for E in (100, 200, 300, 400):
             j = int(order[np.searchsorted(rs_c[order], E, side="left")])
             s1, e1 = cw[j:j + 1].contiguous(), era[j:j + 1].contiguous()

@@ -29,17 +29,24 @@ def main():
     n, k, _ = ctx.code_info(h)
     F = 4096
     dev = torch.device("cuda", 0)
-    for S in (1, 64, 1024):
+    cases = [(1, "uniform"), (64, "uniform"), (1024, "uniform"), (1024, "cfg3")]
+    if len(sys.argv) > 1 and sys.argv[1] == "cfg3":
+        cases = [(1024, "cfg3")]
+    for S, channel in cases:
         src_t = torch.empty((F, k, S), dtype=torch.uint8, device=dev)
         ctx.synth_source(1, 0, F, k, S, src_t)
         cw = ctx.encode(h, src_t if S > 1 else src_t.reshape(F, k))
         era = torch.empty((F, n), dtype=torch.uint8, device=dev)
-        ctx.synth_erasures_uniform(2, 0, F, n, 0.10, era)
-        buf = (C.c_ulonglong * 16)()
+        if channel == "uniform":
+            ctx.synth_erasures_uniform(2, 0, F, n, 0.10, era)
+        else:   # the BASELINE cfg 3 channel of bench.py (frames with E0 >= n-k are simply left undecodable here)
+            ctx.synth_erasures_bursty(20261005 + 1, 0, F, n, 0.13, 0.8, 10.0, era)
+        print(f"--- S={S} channel={channel}")
+        buf = (C.c_ulonglong * 32)()
         L.ldpc_amd_debug_peel_stamps(ctx._h, buf, 1)
         reps = 5
         for _ in range(reps):
-            out, sw, res, st = ctx.decode(h, cw, era)
+            out, sw, res, st = ctx.decode(h, cw, era, do_ml=0)
         L.ldpc_amd_debug_peel_stamps(ctx._h, buf, 1)
         tot = sum(buf[i] for i in range(8))
         print(f"S={S}: {tot / (reps * F):.0f} cycles per frame (sum of phases, s_memtime ticks)")
