@@ -219,7 +219,8 @@ struct PeelArgs {
     int32_t *big_list;      // [0] = count, [1..] frames with more than tcap steps (scatter tier 2), or nullptr
     int tcap;
     // ML hand-off
-    int32_t *ml_list;       // [0] = count, [1..] frame ids
+    int32_t *ml_list;       // [0] = count, [1..4] = counts of the four size classes, [8 + slot] = frame id,
+                            // [8 + nframes + k nframes + i] = slot of the i-th frame of size class k (largest residual first)
     uint8_t *ml_state;      // [slot][n]  1 = still erased
 };
 
@@ -328,7 +329,10 @@ __global__ __launch_bounds__(1024) void ldpc_peel_kernel(PeelArgs a)
             int slot = 0;
             if (lane == 0) {
                 slot = atomicAdd(&a.ml_list[0], 1);
-                a.ml_list[1 + slot] = (int32_t)f;
+                a.ml_list[8 + slot] = (int32_t)f;
+                // size classes: the ML kernel hands out the large systems first (its run time is the slowest workgroup's)
+                const int k_ = remaining * 10 >= m * 6 ? 0 : (remaining * 20 >= m * 9 ? 1 : (remaining * 10 >= m * 3 ? 2 : 3));
+                a.ml_list[8 + a.nframes + (int64_t)k_ * a.nframes + atomicAdd(&a.ml_list[1 + k_], 1)] = slot;
             }
             slot = (int)uniform((uint32_t)slot);
             uint8_t *ms = a.ml_state + (int64_t)slot * n;
@@ -1470,9 +1474,9 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
 
     const int64_t nf = d.nframes;
     int rc;
-    if ((rc = scratch_reserve(ctx, ctx->mllist, sizeof(int32_t) * (size_t)(nf + 1)))) return rc;
+    if ((rc = scratch_reserve(ctx, ctx->mllist, sizeof(int32_t) * (size_t)(5 * nf + 8)))) return rc;
     if (d.do_ml && (rc = scratch_reserve(ctx, ctx->mlstate, (size_t)nf * cd.n))) return rc;
-    LDPC_HIP_TRY(ctx, hipMemsetAsync(ctx->mllist.p, 0, sizeof(int32_t), ctx->stream));
+    LDPC_HIP_TRY(ctx, hipMemsetAsync(ctx->mllist.p, 0, 8 * sizeof(int32_t), ctx->stream));
     if (use_scatter && plan.two_tier) {
         if ((rc = scratch_reserve(ctx, ctx->biglist, sizeof(int32_t) * (size_t)(nf + 1)))) return rc;
         LDPC_HIP_TRY(ctx, hipMemsetAsync(ctx->biglist.p, 0, sizeof(int32_t), ctx->stream));
@@ -1539,7 +1543,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         MlArgs ma{};
         ma.code = cd; ma.S = d.S;
         ma.Spad = fused ? 16 : d.S;
-        ma.ml_list = (const int32_t *)ctx->mllist.p; ma.ml_state = (const uint8_t *)ctx->mlstate.p;
+        ma.ml_list = (const int32_t *)ctx->mllist.p; ma.ml_state = (const uint8_t *)ctx->mlstate.p; ma.nframes = nf;
         ma.out = d.out; ma.status = d.status;
         const int maxrow = align_up(cd.m, 16) + 32;
         ma.maxrow = maxrow;
@@ -1577,6 +1581,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         int solve_b = 0;
         if (ma.use_solve) {
             solve_b = 128;
+            if (const char *e = getenv("LDPC_AMD_ML_SOLVE_B")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64 || v == 128) solve_b = v; }   // A/B knob
             while (solve_b > 16 && (d.S % solve_b) != 0) solve_b >>= 1;
             const int tail_sv = align_up(4 * (2 * cd.m + 6), 16) + 8192 + 64;
             while (solve_b > 16 && cd.m * solve_b + tail_sv > 79 * 1024) solve_b >>= 1;
@@ -1611,7 +1616,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             sv.lds_tab = o; o += align_up(4 * (2 * cd.m + 6), 16);
             sv.lds_mt = o; o += 8192;
             sv.lds_misc = o; o += 64;
-            const int per_cu = std::max(1, std::min(2, kLdsMax / o));
+            const int per_cu = std::max(1, std::min(4, kLdsMax / o));
             const dim3 sg((unsigned)std::min<int64_t>(nf * sv.nslices, (int64_t)ctx->sm_count * per_cu));
 #define LDPC_ML_SOLVE(LPRV)                                                                                   \
     {                                                                                                        \
