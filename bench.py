@@ -388,7 +388,7 @@ def run_cfg2(g, args):
     h, n, k = g.code(1)
     F = args.frames
     result = {}
-    for S in ([args.S, 1] if args.S != 1 else [1]):
+    for S in ([args.S, 1] if (args.S != 1 and not args.no_s1) else [args.S]):
         steps = args.steps if S == args.S else max(args.steps, 20)
         cw, sym, era, _ = g.make_batch("cfg2", 1, S, frame0=g.rank * F, nframes=F)   # every rank its own frames
         counts = [F] * g.world
@@ -583,6 +583,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="CPU-baseline decode time per worker and leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="headline only (skip the cfg 3/4/5 block)")
+    ap.add_argument("--no-s1", action="store_true", help="skip the S = 1 companion runs (profiling of one batch shape)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -605,8 +606,8 @@ def main():
                 cpu[("cfg2", 1)] = cpu_baseline("cfg2", 1, T)
             cpu["cfg1"] = cpu_cfg1()
         if want_block or args.config == "3":
-            cpu[("cfg3", 1024)] = cpu_baseline("cfg3", 1024, T)
-            cpu[("cfg3", 1)] = cpu_baseline("cfg3", 1, T)
+            for S_ in sorted({1024, 1} if want_block else ({args.S} if args.no_s1 else {args.S, 1}), reverse=True):
+                cpu[("cfg3", S_)] = cpu_baseline("cfg3", S_, T)
         if want_block or args.config == "4":
             cpu[("cfg4", 1)] = cpu_baseline("cfg4", 1, T)
         if want_block or args.config == "5":
@@ -627,7 +628,7 @@ def main():
             block["cfg5"] = run_cfg5(g, args, WORKLOADS["cfg5"]["frames"] // 8, args.gather)
             block["cfg5"]["workload"] += " -- ONE GPU's share (1/8) of the 8-GPU job; `--config 5 --gpus 8` runs the whole stream"
     elif args.config == "3":
-        block = {f"cfg3_S{S}": run_cfg3(g, args, S) for S in sorted({args.S, 1}, reverse=True)}
+        block = {f"cfg3_S{S}": run_cfg3(g, args, S) for S in sorted({args.S} if args.no_s1 else {args.S, 1}, reverse=True)}
     elif args.config == "4":
         block = {"cfg4": run_cfg4(g, args)}
     else:

@@ -710,7 +710,8 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     }
     for (int i = tid; i < 2048; i += nthr) mt[i] = c_mul3[i];
     for (int i = tid; i <= nlev; i += nthr) lvlend[i] = gle[i];
-    for (int i = tid; i < (cd.m + 1) / 2; i += nthr) reinterpret_cast<uint32_t *>(soc)[i] = 0xFFFFFFFFu;
+    if (!a.static_sched)   // (the encoder's lists are in slot form already: it has no check -> slot table)
+        for (int i = tid; i < (cd.m + 1) / 2; i += nthr) reinterpret_cast<uint32_t *>(soc)[i] = 0xFFFFFFFFu;
     if (tid < 2) reinterpret_cast<int *>(smem + a.lds_rowctr)[tid] = 0;   // [0] row-batch counter of the streaming phase, [1] received rows
     for (int i = tid; i < nsteps * LPR; i += nthr) reinterpret_cast<U4 *>(acc)[i] = U4{0, 0, 0, 0};
     // row kinds: 1 received, 2 erased and never solved (written as 0), 0 erased and solved in phase B (set below)
@@ -725,7 +726,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     auto put_step = [&](int s, uint32_t step, uint32_t iv) {
         const uint32_t row = step & 0xFFFFu, t = step >> 16;
         tgt[s] = (uint16_t)t;
-        soc[row] = (uint16_t)s;
+        if (!a.static_sched) soc[row] = (uint16_t)s;
         invc[s] = (uint8_t)iv;
         rk[t] = 0;
     };
@@ -754,7 +755,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     // which are pulled into registers first.  Rows that were erased and are never solved are zeroed here.
     uint16_t *rlist = reinterpret_cast<uint16_t *>(rk);
     int nrecv = 0;
-    const bool list_mode = a.dyn_rows == 2 && n <= EPT * nthr;
+    const bool list_mode = a.dyn_rows == 2 && n <= EPT * nthr && !a.static_sched;
     if (list_mode) {
         int *nrecv_p = reinterpret_cast<int *>(smem + a.lds_rowctr) + 1;
         uint32_t kd[EPT];
@@ -1364,7 +1365,7 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
     }
 #undef LDPC_SCATTER_T1
     LDPC_HIP_TRY(ctx, hipGetLastError());
-    if (p.two_tier) {
+    if (p.two_tier && big_list) {
         sa.tcap = sa.code.m; sa.nslots = sa.code.m; sa.big_list = big_list;
         scatter_set_lds(sa, p, sa.code.m);
         const dim3 g2((unsigned)std::min<int64_t>(sa.nframes * sa.nslices, ctx->sm_count));
@@ -1656,6 +1657,27 @@ int launch_encode(ldpc_amd_ctx *ctx, const DevCode &cd, int S, int64_t nframes, 
         ScatterPlan plan = plan_scatter(cd, S);
         if (plan.lpr > 0) {
             plan.two_tier = false; plan.tcap = cd.m; plan.lds1 = plan.lds2;
+            // The encoder needs all m accumulators (every check is a step), which at 256-byte row pieces fills the LDS with
+            // ONE workgroup per CU.  With 128-byte pieces and the tables the static schedule does not need left out (check ->
+            // slot table, received-row list) two workgroups fit, and one streams while the other runs its 27 levels.
+            const char *env_eb = getenv("LDPC_AMD_ENC_B");
+            const int eb = env_eb ? atoi(env_eb) : 128;
+            if (plan.lpr == 16 && eb == 128 && (S % 128) == 0) {
+                ScatterPlan q = plan;
+                int off = 0;
+                q.o_tgt = off; off += align_up(2 * cd.m, 16);
+                q.o_invc = off; off += align_up(cd.m, 16);
+                q.o_lvl = off; off += align_up(2 * (cd.m + 2), 16);
+                q.o_ctr = off; off += 16;
+                q.o_mt = off; off += 8192;
+                q.o_soc = off; off += align_up(cd.n, 16);   // row kinds only (u8)
+                q.o_chk = off;                               // unused in static mode
+                if (cd.m * 128 + off <= kLdsMax / 2) {
+                    q.lpr = 8; q.nslices = S / 128; q.lds1 = q.lds2 = cd.m * 128 + off;
+                    q.two_tier = true;    // (only selects the 8-waves-per-SIMD instantiation; tcap = m: no frame goes to tier 2)
+                    plan = q;
+                }
+            }
             ScatterArgs sa{};
             sa.code = cd; sa.S = S; sa.nslices = plan.nslices; sa.nframes = nframes; sa.sym = src; sa.erased = nullptr; sa.out = cw;
             sa.in_rows = cd.k; sa.static_sched = 1;

@@ -47,8 +47,11 @@ def main():
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--note", default="")
+    ap.add_argument("--valu", help="directory of a --pmc VALUBusy pass -> <tag>_valubusy.json")
+    ap.add_argument("--outdir", default=None, help="where the summaries go (default: profiles/)")
+    ap.add_argument("--cmd", default="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline", help="the profiled command (for the note)")
     a = ap.parse_args()
-    out = os.path.join(ROOT, "profiles")
+    out = a.outdir or os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     if a.stats:
         src = find(a.stats, "*kernel_stats.csv")
@@ -60,8 +63,7 @@ def main():
     if a.fetch and a.write:
         fe = pmc_mean(find(a.fetch, "*counter_collection.csv"), "FETCH_SIZE")
         wr = pmc_mean(find(a.write, "*counter_collection.csv"), "WRITE_SIZE")
-        summ = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `python3 bench.py --steps 2 "
-                        "--warmup 1 --no-cpu-baseline`; values per launch. FETCH_SIZE/WRITE_SIZE are reported in KB; "
+        summ = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of `" + a.cmd + "`; values per launch. FETCH_SIZE/WRITE_SIZE are reported in KB; "
                         "fetch_bytes = 2 * FETCH_SIZE * 1024 (gfx950: wide coalesced reads are tallied at half), "
                         "write_bytes = WRITE_SIZE * 1024. For kernels launched with different batch shapes in one run "
                         "(peel: S=1 and packet batches) the mean mixes them; the max is the largest launch. " + a.note,
@@ -77,6 +79,14 @@ def main():
             json.dump(summ, f, indent=1)
         for k, v in summ["kernels"].items():
             print(f"{k:45s} traffic/launch {v['traffic_bytes'] / 1e9:8.3f} GB")
+    if a.valu:
+        vb = pmc_mean(find(a.valu, "*counter_collection.csv"), "VALUBusy")
+        summ = {"note": "rocprofv3 --pmc VALUBusy (own pass), mean over the launches of each kernel, percent of cycles the vector "
+                        "ALUs were busy", "kernels": {k: {"VALUBusy_pct": v[0], "launches": v[1], "max": v[2]} for k, v in sorted(vb.items())}}
+        with open(os.path.join(out, f"{a.tag}_valubusy.json"), "w") as f:
+            json.dump(summ, f, indent=1)
+        for k, v in summ["kernels"].items():
+            print(f"{k:45s} VALUBusy {v['VALUBusy_pct']:6.1f} %")
 
 
 if __name__ == "__main__":
