@@ -198,6 +198,11 @@ int ldpc_amd_get_profile(ldpc_amd_ctx *ctx, double ms[LDPC_AMD_PROF_KINDS], int6
  * launch of that kind used -- the launch plan depends on code, S and batch, so a report must not hard-code it.
  * "" when no kernel of the kind was launched yet. */
 const char *ldpc_amd_profile_kernel_name(ldpc_amd_ctx *ctx, int kind);
+/* Launch plan of the last ldpc_amd_decode_batch (of its last chunk): info[0] frames (= wavefronts) per peel workgroup,
+ * [1] frames resident per CU, [2] 1 = code tables read from global memory instead of LDS, [3] peel LDS bytes per workgroup,
+ * [4] peel LDS bytes per frame, [5] bytes of every row per packet-kernel workgroup (0: no packet kernel), [6] accumulator
+ * cap of tier 1, [7] 1 = two tiers.  Diagnostic (tools/tune_s1.py); no reference counterpart. */
+int ldpc_amd_last_plan(ldpc_amd_ctx *ctx, int info[8]);
 
 /* ---- diagnostics ----------------------------------------------------------------------------------- */
 /* Device self-test of the GF(256) primitives (packed multiply vs. table) -> 0 when all 65536 products and

@@ -962,6 +962,13 @@ const char *ldpc_amd_profile_kernel_name(ldpc_amd_ctx *ctx, int kind)
     return ctx->prof_names[kind].c_str();
 }
 
+int ldpc_amd_last_plan(ldpc_amd_ctx *ctx, int info[8])
+{
+    if (!ctx || !info) return LDPC_AMD_EINVAL;
+    memcpy(info, ctx->last_plan, sizeof(ctx->last_plan));
+    return LDPC_AMD_OK;
+}
+
 // ---- diagnostics ---------------------------------------------------------------------------------------
 int ldpc_amd_selftest(ldpc_amd_ctx *ctx)
 {

@@ -117,6 +117,7 @@ struct ldpc_amd_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[LDPC_AMD_PROF_KINDS];
     std::vector<hipEvent_t> prof_pool;
     std::string prof_names[LDPC_AMD_PROF_KINDS];   // template instantiation the last launch of each kind used
+    int last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // launch plan of the last decode (ldpc_amd_last_plan)
 };
 
 namespace ldpc_amd {

@@ -61,7 +61,7 @@ __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgc
 // Diagnostic build only (-DLDPC_AMD_STAMPS, tools/stamp_peel.py): per-phase cycle sums of the peel kernel go to a
 // buffer nothing else reads.  The product build contains no stamp.
 #ifdef LDPC_AMD_STAMPS
-__device__ unsigned long long g_peel_stamps[32];   // [0..15] peel / packet kernel, [16..31] ML kernel
+__device__ unsigned long long g_peel_stamps[40];   // [0..15] peel / packet kernel, [16..31] ML kernel, [32..39] ML solve kernel
 #define LDPC_STAMP(i)                                                                     \
     do {                                                                                  \
         const unsigned long long t__ = __builtin_amdgcn_s_memtime();                      \
@@ -1473,6 +1473,9 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         }
     }
 
+    ctx->last_plan[0] = wpb; ctx->last_plan[1] = std::min(32, (kLdsMax / L.total) * wpb); ctx->last_plan[2] = gt ? 1 : 0;
+    ctx->last_plan[3] = L.total; ctx->last_plan[4] = L.wave_stride; ctx->last_plan[5] = use_scatter ? plan.lpr * 16 : 0;
+    ctx->last_plan[6] = use_scatter ? plan.tcap : 0; ctx->last_plan[7] = use_scatter && plan.two_tier ? 1 : 0;
     const int64_t nf = d.nframes;
     int rc;
     if ((rc = scratch_reserve(ctx, ctx->mllist, sizeof(int32_t) * (size_t)(5 * nf + 8)))) return rc;
@@ -1791,9 +1794,9 @@ int launch_fpga_halves(ldpc_amd_ctx *ctx, const DevCode &code, int64_t nframes, 
 extern "C" int ldpc_amd_debug_peel_stamps(ldpc_amd_ctx *ctx, unsigned long long *out32, int reset)
 {
     LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    LDPC_HIP_TRY(ctx, hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_peel_stamps), 32 * sizeof(unsigned long long)));
+    LDPC_HIP_TRY(ctx, hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_peel_stamps), 40 * sizeof(unsigned long long)));
     if (reset) {
-        unsigned long long z[32] = {0};
+        unsigned long long z[40] = {0};
         LDPC_HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_peel_stamps), z, sizeof(z)));
     }
     return LDPC_AMD_OK;

@@ -181,3 +181,67 @@ def test_cfg5_mixed_stream_bucketed_and_sharded(tctx, oracle, code_a, code_b):
         o, osw, ores, ost = oracles[cid].decode_batch_s1(sym[None], era[None])
         assert np.array_equal(o[0], out) and osw[0] == sw and ost[0] == st
     assert all(np.array_equal(r[1], r[4]) for r in results.values() if r[3] in (0, 1))
+
+
+# ------------------------------------------------------------------------------------------ full-size batches
+class _Args:
+    pass
+
+
+@pytest.fixture(scope="module")
+def bgpu():
+    """bench.py's own device-side generators (the batches the driver-run bench line is measured on)."""
+    pytest.importorskip("torch")
+    import bench
+    g = bench.Gpu(_Args(), 0, 1, 0)
+    yield g
+    g.close()
+
+
+def _lane(t, lane):
+    return t[:, :, lane].contiguous()
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3"])
+def test_full_4096_frame_packet_batches(bgpu, oracle, code_a, cfg):
+    """BASELINE cfg 2 and cfg 3 at their full size (4096 frames drawn, S = 1024) -- the batches bench.py times -- through
+    size-independent properties: every frame the decoder reports solved equals its codeword; every byte lane of the packet
+    decode equals the S = 1 (Matlab-model) decode of that lane, rank-deficient frames included ("each byte lane
+    of an S > 1 decode must equal an S = 1 decode of that lane with the same pattern"); the packet ML stage's two
+    implementations (solve schedules in LDS slices / inside the ML kernel) agree byte for byte; a few frames of every status
+    are compared with the oracle."""
+    import os
+    import torch
+    g = bgpu
+    h, n, k = g.code(1)
+    cw, sym, era, keep = g.make_batch(cfg, 1, 1024, frame0=0, nframes=4096)
+    F = cw.shape[0]
+    out, sw, res, st = g.ctx.decode(h, sym, era)
+    torch.cuda.synchronize()
+    ok = st <= 1
+    assert torch.equal(out[ok], cw[ok])
+    if cfg == "cfg2":
+        assert F == 4096 and int(st.max()) == 0
+    else:
+        assert F < 4096 and float((res > 0).float().mean()) >= 0.10 and int((st == 2).sum()) > 0   # ML runs, some systems are rank deficient
+        os.environ["LDPC_AMD_ML_SOLVE"] = "0"
+        try:
+            out2, sw2, res2, st2 = g.ctx.decode(h, sym, era)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("LDPC_AMD_ML_SOLVE", None)
+        assert torch.equal(out2, out) and torch.equal(st2, st) and torch.equal(sw2, sw)
+    for lane in (0, 777):
+        o1, sw1, res1, st1 = g.ctx.decode(h, _lane(sym, lane), era)
+        torch.cuda.synchronize()
+        assert torch.equal(sw1, sw) and torch.equal(res1, res) and torch.equal(st1, st)
+        assert torch.equal(o1, _lane(out, lane))
+    oc = oracle.OracleCode(code_a)
+    picks = [0]
+    for code in (1, 2):
+        hit = (st == code).nonzero().flatten()
+        if hit.numel():
+            picks.append(int(hit[0]))
+    for f in picks:
+        o, _, it, info, _ = oc.decode_packets(sym[f].cpu().numpy(), era[f].cpu().numpy())
+        assert np.array_equal(o, out[f].cpu().numpy()) and it == int(sw[f]) and info[0] == int(res[f])

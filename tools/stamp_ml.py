@@ -15,6 +15,8 @@ PHASES = {16: "build", 17: "barrier wait", 18: "step header", 19: "row updates",
           21: "packets: backward levels (one wavefront)", 22: "packets: schedule count pass", 23: "packets: schedule place pass",
           24: "fall-back: forward level sort", 25: "fall-back: forward pull", 26: "fall-back: backward levels + sort",
           27: "back substitution / fall-back backward pull", 28: "write-back"}
+SOLVE = {32: "solve: task pick-up, table, zeroing", 33: "solve: level 0 (known neighbours from HBM)", 34: "solve: forward + backward levels",
+         36: "solve: output level + wait"}
 
 
 def main():
@@ -45,7 +47,7 @@ def main():
         ctx.synchronize()
         rs_c = rs.cpu().numpy()
         order = np.argsort(rs_c)
-        buf = (C.c_ulonglong * 32)()
+        buf = (C.c_ulonglong * 40)()
         for E in (100, 200, 300, 400):
             j = int(order[np.searchsorted(rs_c[order], E, side="left")])
             s1, e1 = cw[j:j + 1].contiguous(), era[j:j + 1].contiguous()
@@ -60,6 +62,11 @@ def main():
             for i, name in PHASES.items():
                 if buf[i]:
                     print(f"   {name:22s} {buf[i] / reps:10.0f} ticks  {100.0 * buf[i] / tot:5.1f} %")
+            stot = sum(buf[i] for i in SOLVE)
+            if stot:
+                print(f"   solve kernel, all slices of the frame, wavefront 0: {stot / reps:.0f} ticks")
+                for i, name in SOLVE.items():
+                    print(f"      {name:46s} {buf[i] / reps:10.0f} ticks  {100.0 * buf[i] / stot:5.1f} %")
         del cw
     ctx.close()
 
