@@ -118,9 +118,11 @@ def _cpu_worker(args):
     frames = blocks = ml = 0
     f = wid
     chunk = 64 if S == 1 else 2
-    while f < F and busy + busy_rs < seconds:
-        ids = list(range(f, min(F, f + chunk * nworkers), nworkers))
-        f = ids[-1] + nworkers
+    while busy + busy_rs < seconds:
+        # worker w takes frames w, w + W, ... of the GPU's batch and starts over at the end (on a many-core host the batch is
+        # only a few frames per worker; every worker still decodes for the stated time)
+        ids = [(f + i * nworkers) % F for i in range(chunk)]
+        f = (ids[-1] + nworkers) % F
         for ci in code_inds:
             c, oc = ocs[ci]
             mine = [g for g in ids if len(code_inds) == 1 or (g % len(code_inds)) == code_inds.index(ci)]
@@ -580,7 +582,7 @@ def main():
                          "(5 = the 65536-frame mixed stream sharded over --gpus ranks)")
     ap.add_argument("--gather", default="status", choices=["status", "outputs"], help="cfg 5: what the final gather moves")
     ap.add_argument("--total-frames", type=int, default=None, help="cfg 5: frames of the whole stream (default 65536)")
-    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="CPU-baseline decode time per worker and leg")
+    ap.add_argument("--cpu-seconds", type=float, default=3.0, help="CPU-baseline decode time per worker and leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="headline only (skip the cfg 3/4/5 block)")
     ap.add_argument("--no-s1", action="store_true", help="skip the S = 1 companion runs (profiling of one batch shape)")

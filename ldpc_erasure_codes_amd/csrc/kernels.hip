@@ -755,26 +755,75 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     // which are pulled into registers first.  Rows that were erased and are never solved are zeroed here.
     uint16_t *rlist = reinterpret_cast<uint16_t *>(rk);
     int nrecv = 0;
-    const bool list_mode = a.dyn_rows == 2 && n <= EPT * nthr && !a.static_sched;
+    // Sorted list mode (a.dyn_rows == 3): the list is additionally ordered by the number of accumulators a row feeds
+    // (its column-list entries whose check is used by a step of this frame), most first.  The four row pieces a wavefront
+    // handles at once then have the same number of edges, so no lane group idles while another finishes its row (with
+    // rows in index order a pass takes max-over-four turns: 2.4 for 1.3 edges per row at 10 % erasures), and the rows
+    // that feed nothing come last and skip the multiply set-up altogether.
+    const bool sorted_mode = a.dyn_rows == 3 && n <= EPT * nthr && !a.static_sched && cdw <= 16;
+    const bool list_mode = (a.dyn_rows == 2 || sorted_mode) && n <= EPT * nthr && !a.static_sched;
     if (list_mode) {
         int *nrecv_p = reinterpret_cast<int *>(smem + a.lds_rowctr) + 1;
-        uint32_t kd[EPT];
+        int *bins = reinterpret_cast<int *>(smem + a.lds_rowctr) + 4;   // [0..16] rows per edge count, [17..33] fill pointers
+        uint32_t kd[EPT], ec[EPT];
 #pragma unroll
         for (int u = 0; u < EPT; u++) {
             const int j = tid + u * nthr;
             kd[u] = (j < n) ? (uint32_t)rk[j] : 0u;
+            ec[u] = 0;
+        }
+        if (sorted_mode) {
+            if (tid < 34) bins[tid] = 0;
+#pragma unroll
+            for (int u = 0; u < EPT; u++) {
+                const int j = tid + u * nthr;
+                if (kd[u] == 1u) {
+                    uint32_t c = 0;
+                    for (int idx = 0; idx < cdw; idx++) {
+                        const uint32_t w = cd.cell[((uint32_t)j << cd.cdw_shift) + (uint32_t)idx];
+                        c += (w != 0xFFFFFFFFu && soc[w & 0xFFFFu] != 0xFFFFu) ? 1u : 0u;
+                    }
+                    ec[u] = c;
+                }
+            }
         }
         __syncthreads();
         uint8_t *fz = a.out + f * (int64_t)n * S + (int64_t)sl * B;
+        if (sorted_mode) {
+#pragma unroll
+            for (int u = 0; u < EPT; u++)
+                for (int c = 0; c <= cdw; c++) {
+                    const uint64_t mask = __ballot(kd[u] == 1u && ec[u] == (uint32_t)c);
+                    if (lane == 0 && mask) atomicAdd(&bins[c], __popcll(mask));
+                }
+            __syncthreads();
+            if (tid == 0) {
+                int run = 0;
+                for (int c = cdw; c >= 0; c--) { bins[17 + c] = run; run += bins[c]; }
+                *nrecv_p = run;
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int u = 0; u < EPT; u++) {
             const int j = tid + u * nthr;
             const bool recv = kd[u] == 1u;
-            const uint64_t mask = __ballot(recv);
-            int base = 0;
-            if (lane == 0 && mask) base = atomicAdd(nrecv_p, __popcll(mask));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (recv) rlist[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)j;
+            if (sorted_mode) {
+                for (int c = 0; c <= cdw; c++) {
+                    const bool mine = recv && ec[u] == (uint32_t)c;
+                    const uint64_t mask = __ballot(mine);
+                    int base = 0;
+                    if (lane == 0 && mask) base = atomicAdd(&bins[17 + c], __popcll(mask));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (mine) rlist[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)j;
+                }
+            } else {
+                const uint64_t mask = __ballot(recv);
+                int base = 0;
+                if (lane == 0 && mask) base = atomicAdd(nrecv_p, __popcll(mask));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (recv) rlist[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)j;
+            }
             if (kd[u] == 2u)
                 for (int q = 0; q < LPR; q++) stream_store16<NT>(fz + (int64_t)j * S + q * 16, U4{0, 0, 0, 0});
         }
@@ -1283,7 +1332,7 @@ static int scatter_tail_bytes(const DevCode &cd, ScatterPlan &p)
     p.o_tgt = off; off += align_up(2 * cd.m, 16);
     p.o_invc = off; off += align_up(cd.m, 16);
     p.o_lvl = off; off += align_up(2 * (cd.m + 2), 16);
-    p.o_ctr = off; off += 16;   // row-batch counter of the streaming phase
+    p.o_ctr = off; off += 160;  // row-batch counter of the streaming phase, received-row count, bins of the sorted list
     p.o_mt = off; off += 8192;
     p.o_soc = off; off += align_up(2 * cd.n, 16);  // row kinds (u8), later the list of received rows (u16)
     p.o_chk = off; off += align_up(2 * (cd.m + 2), 16);  // check -> slot
@@ -1671,7 +1720,7 @@ int launch_encode(ldpc_amd_ctx *ctx, const DevCode &cd, int S, int64_t nframes, 
                 q.o_tgt = off; off += align_up(2 * cd.m, 16);
                 q.o_invc = off; off += align_up(cd.m, 16);
                 q.o_lvl = off; off += align_up(2 * (cd.m + 2), 16);
-                q.o_ctr = off; off += 16;
+                q.o_ctr = off; off += 160;
                 q.o_mt = off; off += 8192;
                 q.o_soc = off; off += align_up(cd.n, 16);   // row kinds only (u8)
                 q.o_chk = off;                               // unused in static mode
