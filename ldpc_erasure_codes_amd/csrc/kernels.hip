@@ -1603,7 +1603,8 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         int off = 0;
         // rlist[3][m] u32; colmap[n] u16 is only alive while rlist[1..2] are not, and shares their bytes
         ma.lds_rlist = off; ma.lds_colmap = off + 4 * cd.m;
-        off += align_up(std::max(12 * cd.m, 4 * cd.m + 2 * cd.n), 16);
+        // (packets: the same bytes later hold the per-level histogram, 2 m + 4 words, and the slot map, m halfwords)
+        off += align_up(std::max(std::max(12 * cd.m, 4 * cd.m + 2 * cd.n), 4 * (2 * cd.m + 4) + 2 * cd.m + 16), 16);
         ma.lds_elist = off; off += align_up(2 * cd.m, 16);
         ma.lds_colv = off; off += align_up(3 * cd.mpad, 16);
         ma.lds_perm = off; off += align_up(2 * cd.m + 2, 16);
@@ -1641,7 +1642,11 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             if (cd.m * solve_b + tail_sv > kLdsMax || cd.n > 65535) ma.use_solve = 0;
         }
         if (ma.use_solve) {
-            const size_t words = std::min<size_t>(std::max<size_t>((size_t)nf * 8192, (size_t)1 << 21), (size_t)1 << 27);   // 64 KB per frame; 16 MB ... 1 GB
+            size_t words = std::min<size_t>(std::max<size_t>((size_t)nf * 8192, (size_t)1 << 21), (size_t)1 << 27);   // 64 KB per frame; 16 MB ... 1 GB
+            if (const char *e = getenv("LDPC_AMD_ML_ARENA_WORDS")) {   // test knob: a small arena makes some frames fall back
+                const long long v = atoll(e);
+                if (v >= 1024) words = (size_t)v;
+            }
             if ((rc = scratch_reserve(ctx, ctx->mlops, words * 8)) || (rc = scratch_reserve(ctx, ctx->mlrec, (size_t)nf * 32))) return rc;
             ma.ops = (unsigned long long *)ctx->mlops.p; ma.ops_cap = words;
             ma.ops_head = (unsigned long long *)(ma.work + 2);
@@ -1883,8 +1888,8 @@ int launch_copy_probe(ldpc_amd_ctx *ctx, const uint8_t *src, uint8_t *dst, uint6
     LDPC_HIP_TRY(ctx, hipEventSynchronize(e1));
     float t = 0.f;
     LDPC_HIP_TRY(ctx, hipEventElapsedTime(&t, e0, e1));
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     *ms = (double)t / reps;
     return LDPC_AMD_OK;
 }
