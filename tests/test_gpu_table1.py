@@ -142,3 +142,37 @@ def test_trio_call_order_is_checked(ctx):
     ctx.data_in(2040, 1, 9, 1, 0)          # empty run
     ctx.ldpc_erasure_decoder(50, 1)
     assert ctx.data_out(1, 0) == (0, 0)
+
+
+def test_paper_figure_bler_curves():
+    """The paper's BLER figure for the (2040,1530) code (Latex/LDPC_triangular_2040_1530_Perf_vs_RS.png, produced by
+    Matlab/LDPCErasureCodes_MessagePassingAlgSim.m:116,134-245 with PER_vec = [0.14 0.16 0.18 0.2 0.22]): binary code, uniform
+    erasures `rand <= PER`, My_LDPC_Erasure_Decoder (50 sweeps) next to My_LDPC_HybridML_Erasure_Decoder (10 sweeps + GF(2)
+    elimination) and the RS(255,192)-equivalent count.  Values read off the figure (log axis, +-25 %): message passing 1e-6 at
+    0.16, 2.7e-3 at 0.18 (where it crosses the RS curve, tex:164), 0.19 at 0.20, 0.87 at 0.22; RS 2.3e-6, 1.3e-4, 2.8e-3, 2.4e-2, 0.12;
+    the MP + ML curve is not visible: no error in the 1e6 / 3.7e5 blocks the script ran at 0.14-0.16 / 0.18.  The only
+    reference-produced numbers that involve the ML stage (GF(2) sibling)."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import paper_figure
+    tctx = api.Context(0)
+    tctx.set_stream(torch.cuda.current_stream().cuda_stream)   # the tool mixes torch ops with library calls: one stream
+    rows = {}
+    for per, nf in ((0.16, 1000000), (0.18, 400000), (0.20, 50000), (0.22, 20000)):
+        r = paper_figure.run(tctx, torch, per, nf, seed=2022)
+        rows[per] = r
+        print(f"\nfigure PER {per:.2f}: MP {r['mp'] / nf:.3g}  MP+ML {r['ml'] / nf:.3g} ({r['skipped']} skipped)  RS {r['rs'] / r['rs_blocks']:.3g}")
+        exact = binom.sf(63, 255, per)
+        ok, pv = consistent_with_rate(r["rs"], r["rs_blocks"], exact)
+        assert ok, f"RS-equivalent BLER at {per}: {r['rs']}/{r['rs_blocks']} vs {exact:.4g} (p = {pv:.2e})"
+    mp = {per: rows[per]["mp"] / rows[per]["frames"] for per in rows}
+    rs = {per: rows[per]["rs"] / rows[per]["rs_blocks"] for per in rows}
+    assert mp[0.16] <= 1e-5                       # figure: 1e-6
+    assert 1.7e-3 <= mp[0.18] <= 3.6e-3           # figure: 2.7e-3
+    assert 0.15 <= mp[0.20] <= 0.26               # figure: 0.19
+    assert 0.80 <= mp[0.22] <= 0.93               # figure: 0.87
+    assert mp[0.16] < rs[0.16] and mp[0.20] > rs[0.20] and 0.5 < mp[0.18] / rs[0.18] < 1.5   # the curves cross at 18 % (tex:164)
+    assert rows[0.16]["ml"] == 0 and rows[0.18]["ml"] == 0                                   # MP + ML: no error observed
+    assert all(rows[per]["ml"] / rows[per]["frames"] < rs[per] for per in rows)              # ... and below RS at all PERs (tex:164)
+    tctx.close()
