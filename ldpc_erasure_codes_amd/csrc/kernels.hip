@@ -1658,7 +1658,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         int ml_threads = 1024;
         if (const char *e = getenv("LDPC_AMD_ML_THREADS")) {
             const int v = atoi(e);
-            if (v == 256 || v == 512 || v == 1024) ml_threads = v;
+            if (v >= 256 && v <= 1024 && (v % 64) == 0) ml_threads = v;
         }
         auto kfn = ldpc_ml_kernel;
         LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(kfn)));
