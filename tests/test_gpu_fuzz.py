@@ -2,6 +2,8 @@
 the gather kernel, fewer checks than a wavefront, n of no convenient multiple), S = 1 and packets, erasure rates from
 'nothing to do' to 'ML stage, some rank-deficient' -- the GPU must equal the oracle bit for bit on every frame,
 `iterations`, residual counts and status words included."""
+import os
+
 import numpy as np
 import pytest
 
@@ -34,12 +36,16 @@ def random_code(rng):
     return codes.from_dense(H, k)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("LDPC_FUZZ_SEEDS", "12"))))   # LDPC_FUZZ_SEEDS=200: a longer soak
 def test_random_codes_match_the_oracle(ctx, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     for _ in range(3):
         code = random_code(rng)
         n, k = code.n, code.k
+        if int(np.diff(code.row_ptr.astype(np.int64)).max()) > 24:
+            with pytest.raises(api.LdpcAmdError):   # heavy columns on top of 24 random ones: beyond the kernels' row degree
+                ctx.register_code(code)
+            continue
         h = ctx.register_code(code)
         oc = oracle.OracleCode(code)
         F = 6
