@@ -179,3 +179,22 @@ def test_world_size_2_gloo_mixed_stream_code_a_and_b(total, what):
             assert np.array_equal(out, o) and np.array_equal(out[st <= 1], cw[st <= 1])
         else:
             assert out is None
+
+
+# ------------------------------------------------------------------------------------------------------------
+# bench.py's CPU-baseline legs (they run before the GPU is touched; a failure there would cost the whole bench line)
+# ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg,S", [("cfg2", 1), ("cfg2", 64), ("cfg3", 1), ("cfg4", 1), ("cfg5", 1)])
+def test_bench_cpu_baseline_workers(cfg, S):
+    """One CPU-baseline worker of bench.py per BASELINE config, for a fraction of a second: decodes frames of the GPU's own
+    batch with the oracle, checks them against the codewords, and reports (frames, seconds, RS blocks, seconds, ML frames)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    frames, busy, blocks, busy_rs, ml = bench._cpu_worker((1, 3, cfg, S, 0.15))
+    assert frames > 0 and busy > 0
+    if cfg == "cfg4":
+        assert blocks > 0 and busy_rs > 0
+    if cfg == "cfg3":
+        assert ml > 0          # the bursty batch does reach the ML stage
+    r = bench.cpu_cfg1(reps=5)
+    assert r["frames"] == 5 and r["decoded"] >= 4
