@@ -1418,20 +1418,23 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
         sa.tcap = sa.code.m; sa.nslots = sa.code.m; sa.big_list = big_list;
         scatter_set_lds(sa, p, sa.code.m);
         const dim3 g2((unsigned)std::min<int64_t>(sa.nframes * sa.nslices, ctx->sm_count));
-        const char *env_r2 = getenv("LDPC_AMD_SCATTER_R2");   // rows in flight per lane group in tier 2 (128-VGPR budget)
-        const bool r2_4 = LPR == 16 && env_r2 && atoi(env_r2) == 4;
-#define LDPC_SCATTER_T2(NTV, IPV)                                                                            \
-    if (r2_4) {                                                                                              \
-        auto kfn = ldpc_scatter_big_kernel<LPR, (LPR == 16 ? 4 : R), NTV, IPV>;                                   \
-        LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(kfn)));                               \
-        hipLaunchKernelGGL(kfn, g2, dim3(THREADS), (size_t)p.lds2, ctx->stream, sa);                         \
-    } else {                                                                                                 \
-        auto kfn = ldpc_scatter_big_kernel<LPR, R, NTV, IPV>;                                                     \
+        // tier 2 runs one workgroup per CU (4 waves per SIMD, 128 VGPRs each): four row pieces in flight per lane group
+        // instead of two make up for part of the missing occupancy (cfg 3: 4.42 -> 4.19 ms); LDPC_AMD_SCATTER_R2=2 restores two
+        const char *env_r2 = getenv("LDPC_AMD_SCATTER_R2");
+        const int r2 = LPR == 16 ? (env_r2 ? atoi(env_r2) : 4) : 0;
+#define LDPC_SCATTER_T2_R(RV, NTV, IPV)                                                                      \
+    {                                                                                                        \
+        auto kfn = ldpc_scatter_big_kernel<LPR, RV, NTV, IPV>;                                               \
         LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(kfn)));                               \
         hipLaunchKernelGGL(kfn, g2, dim3(THREADS), (size_t)p.lds2, ctx->stream, sa);                         \
     }
+#define LDPC_SCATTER_T2(NTV, IPV)                                                                            \
+    if (r2 == 4) LDPC_SCATTER_T2_R((LPR == 16 ? 4 : R), NTV, IPV)                                            \
+    else if (r2 == 3) LDPC_SCATTER_T2_R((LPR == 16 ? 3 : R), NTV, IPV)                                       \
+    else LDPC_SCATTER_T2_R(R, NTV, IPV)
         if (ip) { if (nt) LDPC_SCATTER_T2(true, true) else LDPC_SCATTER_T2(false, true) }
         else { if (nt) LDPC_SCATTER_T2(true, false) else LDPC_SCATTER_T2(false, false) }
+#undef LDPC_SCATTER_T2_R
 #undef LDPC_SCATTER_T2
         LDPC_HIP_TRY(ctx, hipGetLastError());
     }
