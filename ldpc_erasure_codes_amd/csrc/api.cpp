@@ -284,6 +284,18 @@ static int register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_pt
                 enc_src[((size_t)j << cdw_shift) + fillc[j]++] = slot_of_row[r] | ((uint32_t)hc->coefs[e] << 16);
             }
     }
+    // encoder: source rows in the order of their column degree (every check is a step of the static schedule, so a row's
+    // degree IS the number of accumulators it feeds): the row pieces a wavefront handles at once then take the same number
+    // of edge turns
+    std::vector<uint16_t> enc_order(std::max(k, 1), 0);
+    {
+        std::vector<int> cdeg(n, 0);
+        for (int e = 0; e < hc->nnz; e++) cdeg[cols[e]]++;
+        std::vector<int> idx(k);
+        for (int j = 0; j < k; j++) idx[j] = j;
+        std::stable_sort(idx.begin(), idx.end(), [&](int a_, int b_) { return cdeg[a_] > cdeg[b_]; });
+        for (int j = 0; j < k; j++) enc_order[j] = (uint16_t)idx[j];
+    }
     DevCode &d = hc->dev;
     d.n = n; d.k = k; d.m = m; d.nnz = hc->nnz; d.maxdeg = maxdeg; d.degpad = degpad; d.mpad = mpad;
     d.maxcoldeg = maxcoldeg; d.cdw_shift = cdw_shift;
@@ -292,7 +304,7 @@ static int register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_pt
     if ((rc = upload(ctx, hc, hc->row_ptr, &d.row_ptr)) || (rc = upload(ctx, hc, edges, &d.edges)) ||
         (rc = upload(ctx, hc, ell_col, &d.ell_col)) || (rc = upload(ctx, hc, ell_logc, &d.ell_logc)) ||
         (rc = upload(ctx, hc, ell_coef, &d.ell_coef)) || (rc = upload(ctx, hc, ell_pk, &d.ell_pk)) || (rc = upload(ctx, hc, cell, &d.cell)) ||
-        (rc = upload(ctx, hc, enc_src, &d.enc_src)) || (rc = upload(ctx, hc, enc_invc, &d.enc_invc)) ||
+        (rc = upload(ctx, hc, enc_src, &d.enc_src)) || (rc = upload(ctx, hc, enc_order, &d.enc_order)) || (rc = upload(ctx, hc, enc_invc, &d.enc_invc)) ||
         (rc = upload(ctx, hc, enc_steps, &d.enc_steps)) || (rc = upload(ctx, hc, enc_lvlend, &d.enc_lvlend))) {
         free_code(hc);
         return rc;
