@@ -255,3 +255,25 @@ def test_full_4096_frame_packet_batches(bgpu, oracle, code_a, cfg):
     for f in picks:
         o, _, it, info, _ = oc.decode_packets(sym[f].cpu().numpy(), era[f].cpu().numpy())
         assert np.array_equal(o, out[f].cpu().numpy()) and it == int(sw[f]) and info[0] == int(res[f])
+
+
+def test_long_batch_crosses_the_internal_chunks(bgpu):
+    """Batches above 16 384 frames are processed in chunks that share the per-call workspaces (schedules, ML lists, the arena
+    of the ML solve schedules): a 40 000-frame bursty batch (S = 64, ML stage on a quarter of the frames) must decode exactly
+    like its two halves decoded separately, and every solved frame must equal its codeword."""
+    import torch
+    g = bgpu
+    h, n, k = g.code(1)
+    cw, sym, era, keep = g.make_batch("cfg3", 1, 64, frame0=0, nframes=40000)
+    F = cw.shape[0]
+    assert F > 2 * 16384
+    out, sw, res, st = g.ctx.decode(h, sym, era)
+    torch.cuda.synchronize()
+    assert float((res > 0).float().mean()) > 0.1
+    ok = st <= 1
+    assert torch.equal(out[ok], cw[ok])
+    half = F // 2
+    for lo, hi in ((0, half), (half, F)):
+        o2, sw2, res2, st2 = g.ctx.decode(h, sym[lo:hi].contiguous(), era[lo:hi].contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(o2, out[lo:hi]) and torch.equal(st2, st[lo:hi]) and torch.equal(sw2, sw[lo:hi]) and torch.equal(res2, res[lo:hi])
