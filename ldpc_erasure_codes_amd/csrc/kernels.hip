@@ -1648,6 +1648,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         // Frames whose schedule does not fit the arena are solved inside the ML kernel (same bytes, slower).
         const char *env_sv = getenv("LDPC_AMD_ML_SOLVE");
         ma.use_solve = (!fused && !(env_sv && atoi(env_sv) == 0)) ? 1 : 0;
+        if (const char *e = getenv("LDPC_AMD_ML_DBG")) ma.dbg = atoi(e);
         int solve_b = 0;
         if (ma.use_solve) {
             solve_b = 128;
