@@ -1634,6 +1634,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         ma.lds_lvl = off; off += align_up(4 * (cd.m + 2), 16);
         ma.lds_A = off;
         if (off > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "ML stage: LDS need %d bytes", off);
+        if (cd.m > 4096) return set_error(ctx, LDPC_AMD_EUNSUP, "ML stage: more than 4096 checks (%d)", cd.m);   // 12-bit row fields of the pivot key
         ma.capA = (kLdsMax - off) & ~15;
         const int total = kLdsMax;
         int grid = (int)std::min<int64_t>(nf, (int64_t)ctx->sm_count);
