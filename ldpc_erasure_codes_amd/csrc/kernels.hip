@@ -1688,6 +1688,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             MlSolveArgs sv{};
             sv.code = cd; sv.S = d.S; sv.nslices = d.S / solve_b; sv.ml_list = ma.ml_list; sv.rec = ma.rec; sv.ops = ma.ops;
             sv.out = d.out; sv.work = ma.work + 4;
+            sv.dbg = ma.dbg;
             int o = cd.m * solve_b;
             sv.lds_tab = o; o += align_up(4 * (2 * cd.m + 6), 16);
             sv.lds_mt = o; o += 8192;

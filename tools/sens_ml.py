@@ -2,7 +2,8 @@
 """Diagnostic (-DLDPC_AMD_MLDBG build): sensitivity of the ML factorisation to its parts, S = 1 on the cfg 3 batch.  LDPC_AMD_ML_DBG bits:
 1 untouched-row scan twice, 2 a second barrier per column, 4 row update twice, 8 four more dependent LDS round trips on the row-update
 chain, 64 the two same-address atomics twice, 128 four more round trips on the bookkeeping thread, 256 four more in every wavefront's
-header, 16 no column at all, 32 stop after half of the columns.  Never quote this build's run time."""
+header, 16 no column at all, 32 stop after half of the columns; solve kernel (S = 1024): 512 / 1024 the multiply-accumulates of
+level 0 / of the later levels three times, 2048 a second barrier per level.  Never quote this build's run time."""
 import os, subprocess, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -30,3 +31,19 @@ for rnd in range(5):
         if rnd: res.setdefault(dbg, []).append(t)
 for dbg, v in res.items():
     print(f"dbg {dbg}: ML kernel {statistics.median(v):.3f} ms")
+# the solve kernel (packets): 512 level-0 multiply-accumulates three times, 1024 the later levels' three times, 2048 a second barrier
+# per level (the ML stage's time is factor + solve; the factor part does not change with these bits)
+del cw, sym, era, out
+cw, sym, era, _ = g.make_batch("cfg3", 1, 1024, frame0=0, nframes=4096)
+out = torch.empty_like(sym)
+res = {}
+for rnd in range(4):
+    for dbg in (0, 512, 1024, 2048):
+        os.environ["LDPC_AMD_ML_DBG"] = str(dbg)
+        g.ctx.get_profile(); g.ctx.set_profiling(True)
+        g.ctx.decode(h, sym, era, out=out)
+        g.ctx.set_profiling(False)
+        t = g.ctx.get_profile()["ml"][0]
+        if rnd: res.setdefault(dbg, []).append(t)
+for dbg, v in res.items():
+    print(f"S=1024 dbg {dbg}: ML stage (factor + solve) {statistics.median(v):.3f} ms")
