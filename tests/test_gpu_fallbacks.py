@@ -89,3 +89,18 @@ def test_device_bursty_channel_equals_sequential_chain(ctx, oracle):
         want = oracle.synth_erasures_bursty(31, frame0, nframes, n, alpha, beta, 10.0)
         assert np.array_equal(d.cpu().numpy(), want)
         assert np.array_equal(want, synth.erasures_bursty(31, frame0, nframes, n, alpha, beta, 10.0))
+
+
+def test_ml_solve_kernel_geometries(ctx, oracle, code_b):
+    """The packet ML stage's solve kernel picks its slice width from the number of checks: 128-byte slices for the (2040,1530)
+    code, 32-byte slices for the (4080,3060) code, 16-byte slices for the (4000,2000) code.  Each geometry against the oracle,
+    with residual systems that exist (status 1 or 2), at a packet size that gives several slices per row."""
+    hb = ctx.load_builtin_code(2, codes.DEFAULT_COEF_SEED[2])
+    st = check_packets(ctx, oracle, code_b, hb, 64, [0.46, 0.475, 0.30], 410)
+    assert (st >= 1).any()
+    if codes.have_builtin(3):
+        code_c = codes.load_builtin(3)
+        hc = ctx.load_builtin_code(3, codes.DEFAULT_COEF_SEED[3])
+        st = check_packets(ctx, oracle, code_c, hc, 64, [0.215, 0.225, 0.23, 0.10], 420)
+        assert (st >= 1).any()
+        st = check_packets(ctx, oracle, code_c, hc, 1024, [0.22], 430)
