@@ -2,7 +2,8 @@
 """Diagnostic (-DLDPC_AMD_MLDBG build): sensitivity of the ML factorisation to its parts, S = 1 on the cfg 3 batch.  LDPC_AMD_ML_DBG bits:
 1 untouched-row scan twice, 2 a second barrier per column, 4 row update twice, 8 four more dependent LDS round trips on the row-update
 chain, 64 the two same-address atomics twice, 128 four more round trips on the bookkeeping thread, 256 four more in every wavefront's
-header, 16 no column at all, 32 stop after half of the columns; solve kernel (S = 1024): 512 / 1024 the multiply-accumulates of
+header, 16 no column at all, 32 stop after half of the columns, 4096 E extra empty steps (barrier + header read), 8192 E extra steps with a
+row update by every lane group; solve kernel (S = 1024): 512 / 1024 the multiply-accumulates of
 level 0 / of the later levels three times, 2048 a second barrier per level.  Never quote this build's run time."""
 import os, subprocess, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,7 +23,7 @@ cw, sym, era, _ = g.make_batch("cfg3", 1, 1, frame0=0, nframes=4096)
 out = torch.empty_like(sym)
 res = {}
 for rnd in range(5):
-    for dbg in (0, 1, 2, 4, 8, 64, 128, 256, 16, 32):
+    for dbg in (0, 1, 2, 4, 8, 64, 128, 256, 16, 32, 4096, 8192):
         os.environ["LDPC_AMD_ML_DBG"] = str(dbg)
         g.ctx.get_profile(); g.ctx.set_profiling(True)
         g.ctx.decode(h, sym, era, out=out)
