@@ -607,13 +607,20 @@ def main():
             if args.S != 1:
                 cpu[("cfg2", 1)] = cpu_baseline("cfg2", 1, T)
             cpu["cfg1"] = cpu_cfg1()
+        def side_leg(cfg, S_):   # a failing side config must not cost the headline line: it is reported, not raised
+            try:
+                cpu[(cfg, S_)] = cpu_baseline(cfg, S_, T)
+            except Exception as e:   # noqa: BLE001
+                if not want_block:
+                    raise
+                print(f"bench.py: CPU baseline of {cfg} S={S_} failed: {e!r}", file=sys.stderr)
         if want_block or args.config == "3":
             for S_ in sorted({1024, 1} if want_block else ({args.S} if args.no_s1 else {args.S, 1}), reverse=True):
-                cpu[("cfg3", S_)] = cpu_baseline("cfg3", S_, T)
+                side_leg("cfg3", S_)
         if want_block or args.config == "4":
-            cpu[("cfg4", 1)] = cpu_baseline("cfg4", 1, T)
+            side_leg("cfg4", 1)
         if want_block or args.config == "5":
-            cpu[("cfg5", 1)] = cpu_baseline("cfg5", 1, T)
+            side_leg("cfg5", 1)
 
     g = Gpu(args, rank, world, local_rank)
     line = None
@@ -622,13 +629,21 @@ def main():
         result, n, k = run_cfg2(g, args)
         block = {}
         if want_block:
+            def side(name, fn):   # the side configs ride along: an exception there is reported in the block, the headline stays
+                try:
+                    r = fn()
+                    if r:
+                        block[name] = r
+                except Exception as e:   # noqa: BLE001
+                    import traceback
+                    traceback.print_exc()
+                    block[name + "_error"] = repr(e)
             for S in (1024, 1):
-                block[f"cfg3_S{S}"] = run_cfg3(g, args, S)
-            c4 = run_cfg4(g, args)
-            if c4:
-                block["cfg4"] = c4
-            block["cfg5"] = run_cfg5(g, args, WORKLOADS["cfg5"]["frames"] // 8, args.gather)
-            block["cfg5"]["workload"] += " -- ONE GPU's share (1/8) of the 8-GPU job; `--config 5 --gpus 8` runs the whole stream"
+                side(f"cfg3_S{S}", lambda S=S: run_cfg3(g, args, S))
+            side("cfg4", lambda: run_cfg4(g, args))
+            side("cfg5", lambda: run_cfg5(g, args, WORKLOADS["cfg5"]["frames"] // 8, args.gather))
+            if "cfg5" in block:
+                block["cfg5"]["workload"] += " -- ONE GPU's share (1/8) of the 8-GPU job; `--config 5 --gpus 8` runs the whole stream"
     elif args.config == "3":
         block = {f"cfg3_S{S}": run_cfg3(g, args, S) for S in sorted({args.S} if args.no_s1 else {args.S, 1}, reverse=True)}
     elif args.config == "4":
@@ -651,6 +666,8 @@ def main():
         for S, r in result.items():
             check(r, 1, S)
     for name, e in block.items():
+        if name.endswith("_error"):
+            continue
         if name.startswith("cfg3"):
             check(e, 1, int(name.split("_S")[1]))
             key = ("cfg3", int(name.split("_S")[1]))
