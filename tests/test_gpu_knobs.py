@@ -1,0 +1,83 @@
+"""Every environment knob of DESIGN.md's appendix, at every non-default value: the library reads the knobs at each call, so
+one process can walk them.  A knob changes HOW a batch is decoded (kernel formulation, tiers, piece sizes, thread counts,
+fall-backs) -- never a byte of the result: outputs, sweep counts, residual counts and status words must equal the default
+run's, which in turn is checked against the oracle.  The batch mixes frames message passing completes, frames that need the
+ML stage and rank-deficient ones, at S = 1 and as packets."""
+import os
+
+import numpy as np
+import pytest
+
+from ldpc_erasure_codes_amd import api, codes, synth
+
+pytestmark = pytest.mark.gpu
+
+KNOBS = [
+    ("LDPC_AMD_APPLY", ["gather"]),
+    ("LDPC_AMD_SCATTER_TIERS", ["1"]),
+    ("LDPC_AMD_SCATTER_B", ["128", "64"]),
+    ("LDPC_AMD_SCATTER_R", ["1", "4"]),
+    ("LDPC_AMD_SCATTER_R2", ["2", "3"]),
+    ("LDPC_AMD_SCATTER_NT", ["0"]),
+    ("LDPC_AMD_SCATTER_XCD", ["0"]),
+    ("LDPC_AMD_SCATTER_DYN", ["0", "2", "3"]),
+    ("LDPC_AMD_ENC_B", ["256"]),
+    ("LDPC_AMD_ENC_LIST", ["1"]),
+    ("LDPC_AMD_PEEL_GT", ["0", "1"]),
+    ("LDPC_AMD_PEEL_WPB", ["1", "4", "16"]),
+    ("LDPC_AMD_ML_SOLVE", ["0"]),
+    ("LDPC_AMD_ML_SOLVE_B", ["64", "32", "16"]),
+    ("LDPC_AMD_ML_ARENA_WORDS", ["20000"]),
+    ("LDPC_AMD_ML_THREADS", ["256", "512", "768"]),
+]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def _batch(code, S, F, seed):
+    src = synth.source(seed, 0, F, code.k, S)
+    # erasure rates from "a few sweeps" over "ML stage" to "rank deficient" for the (2040,1530) code
+    pers = np.linspace(0.05, 0.262, F)
+    era = np.concatenate([synth.erasures_uniform(seed + 1 + i, i, 1, code.n, float(p)) for i, p in enumerate(pers)])
+    return (src if S > 1 else src[:, :, 0]), era
+
+
+@pytest.mark.parametrize("S", [1, 256])
+def test_every_knob_value_gives_the_default_bytes(ctx, oracle, code_a, S):
+    h = ctx.load_builtin_code(1, codes.DEFAULT_COEF_SEED[1])
+    F = 48
+    src, era = _batch(code_a, S, F, 900 + S)
+    saved = {k: os.environ.pop(k) for k, _ in KNOBS if k in os.environ}
+    try:
+        cw0 = ctx.encode(h, src)
+        sym = cw0.copy()
+        sym[era.astype(bool)] = 0x5A
+        ref = ctx.decode(h, sym, era)
+        out0, sw0, res0, st0 = ref
+        assert {0, 1}.issubset(set(st0.tolist())) and st0.max() >= 2      # every kind of frame is in the batch
+        oc = oracle.OracleCode(code_a)
+        for f in (0, F // 2, F - 1):                                       # the default run against the oracle
+            if S == 1:
+                o = oc.decode_batch_s1(sym[f:f + 1], era[f:f + 1])
+                assert np.array_equal(out0[f], o[0][0]) and sw0[f] == o[1][0] and res0[f] == o[2][0] and st0[f] == o[3][0]
+            else:
+                o, _, it, info, rc = oc.decode_packets(sym[f], era[f])
+                assert np.array_equal(out0[f], o) and sw0[f] == it and res0[f] == info[0]
+        for knob, values in KNOBS:
+            for v in values:
+                os.environ[knob] = v
+                try:
+                    cw = ctx.encode(h, src)
+                    assert np.array_equal(cw, cw0), (knob, v, "encode")
+                    out, sw, res, st = ctx.decode(h, sym, era)
+                    assert np.array_equal(sw, sw0) and np.array_equal(res, res0) and np.array_equal(st, st0), (knob, v)
+                    assert np.array_equal(out, out0), (knob, v)
+                finally:
+                    del os.environ[knob]
+    finally:
+        os.environ.update(saved)
