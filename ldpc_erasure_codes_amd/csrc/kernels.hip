@@ -58,6 +58,9 @@ __device__ __forceinline__ void wave_sync()
 
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// residual frames are filed under size classes (ml_list header: count, class counts; then frame ids, then the class lists)
+constexpr int kMlClasses = 16, kMlHdr = 24;
+
 // Diagnostic build only (-DLDPC_AMD_STAMPS, tools/stamp_peel.py): per-phase cycle sums of the peel kernel go to a
 // buffer nothing else reads.  The product build contains no stamp.
 #ifdef LDPC_AMD_STAMPS
@@ -219,8 +222,8 @@ struct PeelArgs {
     int32_t *big_list;      // [0] = count, [1..] frames with more than tcap steps (scatter tier 2), or nullptr
     int tcap;
     // ML hand-off
-    int32_t *ml_list;       // [0] = count, [1..4] = counts of the four size classes, [8 + slot] = frame id,
-                            // [8 + nframes + k nframes + i] = slot of the i-th frame of size class k (largest residual first)
+    int32_t *ml_list;       // [0] = count, [1..kMlClasses] = counts of the size classes, [kMlHdr + slot] = frame id,
+                            // [kMlHdr + nframes + k nframes + i] = slot of the i-th frame of size class k (largest residual first)
     uint8_t *ml_state;      // [slot][n]  1 = still erased
 };
 
@@ -329,10 +332,11 @@ __global__ __launch_bounds__(1024) void ldpc_peel_kernel(PeelArgs a)
             int slot = 0;
             if (lane == 0) {
                 slot = atomicAdd(&a.ml_list[0], 1);
-                a.ml_list[8 + slot] = (int32_t)f;
-                // size classes: the ML kernel hands out the large systems first (its run time is the slowest workgroup's)
-                const int k_ = remaining * 10 >= m * 6 ? 0 : (remaining * 20 >= m * 9 ? 1 : (remaining * 10 >= m * 3 ? 2 : 3));
-                a.ml_list[8 + a.nframes + (int64_t)k_ * a.nframes + atomicAdd(&a.ml_list[1 + k_], 1)] = slot;
+                a.ml_list[kMlHdr + slot] = (int32_t)f;
+                // size classes by residual count: the ML kernel and the solve kernel hand out the large systems first
+                // (their run time is the slowest workgroup's; the last class handed out holds the smallest systems)
+                const int k_ = kMlClasses - 1 - min(kMlClasses - 1, remaining * kMlClasses / m);
+                a.ml_list[kMlHdr + a.nframes + (int64_t)k_ * a.nframes + atomicAdd(&a.ml_list[1 + k_], 1)] = slot;
             }
             slot = (int)uniform((uint32_t)slot);
             uint8_t *ms = a.ml_state + (int64_t)slot * n;
@@ -1543,9 +1547,9 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     ctx->last_plan[6] = use_scatter ? plan.tcap : 0; ctx->last_plan[7] = use_scatter && plan.two_tier ? 1 : 0;
     const int64_t nf = d.nframes;
     int rc;
-    if ((rc = scratch_reserve(ctx, ctx->mllist, sizeof(int32_t) * (size_t)(5 * nf + 8)))) return rc;
+    if ((rc = scratch_reserve(ctx, ctx->mllist, sizeof(int32_t) * ((size_t)(1 + kMlClasses) * nf + kMlHdr)))) return rc;
     if (d.do_ml && (rc = scratch_reserve(ctx, ctx->mlstate, (size_t)nf * cd.n))) return rc;
-    LDPC_HIP_TRY(ctx, hipMemsetAsync(ctx->mllist.p, 0, 8 * sizeof(int32_t), ctx->stream));
+    LDPC_HIP_TRY(ctx, hipMemsetAsync(ctx->mllist.p, 0, kMlHdr * sizeof(int32_t), ctx->stream));
     if (use_scatter && plan.two_tier) {
         if ((rc = scratch_reserve(ctx, ctx->biglist, sizeof(int32_t) * (size_t)(nf + 1)))) return rc;
         LDPC_HIP_TRY(ctx, hipMemsetAsync(ctx->biglist.p, 0, sizeof(int32_t), ctx->stream));
@@ -1686,7 +1690,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         LDPC_HIP_TRY(ctx, hipGetLastError());
         if (ma.use_solve && !(env_sv && atoi(env_sv) == 2)) {   // =2: diagnostic, schedules emitted but not run (timing of the factor part)
             MlSolveArgs sv{};
-            sv.code = cd; sv.S = d.S; sv.nslices = d.S / solve_b; sv.ml_list = ma.ml_list; sv.rec = ma.rec; sv.ops = ma.ops;
+            sv.code = cd; sv.S = d.S; sv.nslices = d.S / solve_b; sv.nframes = nf; sv.ml_list = ma.ml_list; sv.rec = ma.rec; sv.ops = ma.ops;
             sv.out = d.out; sv.work = ma.work + 4;
             sv.dbg = ma.dbg;
             int o = cd.m * solve_b;
