@@ -1634,7 +1634,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         ma.lds_mt = off; off += 8192;
         ma.lds_lg = off; off += 256;
         ma.lds_ex = off; off += 1024;
-        ma.lds_misc = off; off += 128;
+        ma.lds_misc = off; off += 128 + 4 * kMlClasses;
         ma.lds_lvl = off; off += align_up(4 * (cd.m + 2), 16);
         ma.lds_A = off;
         if (off > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "ML stage: LDS need %d bytes", off);
@@ -1659,7 +1659,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             solve_b = 128;
             if (const char *e = getenv("LDPC_AMD_ML_SOLVE_B")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64 || v == 128) solve_b = v; }   // A/B knob
             while (solve_b > 16 && (d.S % solve_b) != 0) solve_b >>= 1;
-            const int tail_sv = align_up(4 * (2 * cd.m + 6), 16) + 8192 + 64;
+            const int tail_sv = align_up(4 * (2 * cd.m + 6), 16) + 8192 + 16 + 4 * kMlClasses;
             while (solve_b > 16 && cd.m * solve_b + tail_sv > 79 * 1024) solve_b >>= 1;
             if (cd.m * solve_b + tail_sv > kLdsMax || cd.n > 65535) ma.use_solve = 0;
         }
@@ -1696,7 +1696,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             int o = cd.m * solve_b;
             sv.lds_tab = o; o += align_up(4 * (2 * cd.m + 6), 16);
             sv.lds_mt = o; o += 8192;
-            sv.lds_misc = o; o += 64;
+            sv.lds_misc = o; o += 16 + 4 * kMlClasses;
             const int per_cu = std::max(1, std::min(4, kLdsMax / o));
             const dim3 sg((unsigned)std::min<int64_t>(nf * sv.nslices, (int64_t)ctx->sm_count * per_cu));
 #define LDPC_ML_SOLVE(LPRV)                                                                                   \
