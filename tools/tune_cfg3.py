@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--S", type=int, nargs="+", default=[1024])
     ap.add_argument("--rounds", type=int, default=4)
+    ap.add_argument("--frames", type=int, default=4096, help="frames drawn from the chain (the BASELINE batch is 4096)")
     ap.add_argument("--variants", type=str, default="", help='JSON: {"name": {"ENV": "value"}, ...}')
     args = ap.parse_args()
     import torch
@@ -32,7 +33,7 @@ def main():
     if args.variants:
         variants.update(json.loads(args.variants))
     for S in args.S:
-        cw, sym, era, _ = g.make_batch("cfg3", 1, S, frame0=0, nframes=4096)
+        cw, sym, era, _ = g.make_batch("cfg3", 1, S, frame0=0, nframes=args.frames)
         F = cw.shape[0]
         out = torch.empty_like(sym)
         st = torch.empty(F, dtype=torch.int32, device=g.dev)
