@@ -627,6 +627,17 @@ __device__ __forceinline__ void lds_xor16(unsigned char *p, const U4 &v, int h)
     __hip_atomic_fetch_xor(q + (1 - h), h ? lo : hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// the same with the two 8-byte targets given as LDS byte addresses (first instruction -> a1, second -> a2; a1 is the lane's
+// half h): no pointer arithmetic on the way to the ds_xor_b64
+__device__ __forceinline__ void lds_xor16_at(uint32_t a1, uint32_t a2, const U4 &v, int h)
+{
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+    const unsigned long long lo = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
+    const unsigned long long hi = (unsigned long long)v.z | ((unsigned long long)v.w << 32);
+    __hip_atomic_fetch_xor(reinterpret_cast<lds_u64 *>((uintptr_t)a1), h ? hi : lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_xor(reinterpret_cast<lds_u64 *>((uintptr_t)a2), h ? lo : hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <bool NT>
 __device__ __forceinline__ U4 stream_load16(const uint8_t *p)
 {
@@ -858,6 +869,9 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
 
     // multiplies v into the accumulators of the steps that symbol j feeds: ew = the symbol's list, entry t held by
     // lane (t % LPR) of the group, 0xFFFFFFFF = no entry.  Every group walks the set bits of its own validity mask.
+    // (entries are in the form to_slots leaves them in: accumulator byte offset | coef << 24; a lane's own 16 bytes of the
+    // accumulator, halves in the bank-friendly order, are OR-ed in: the offset's low bits are free, B >= 64)
+    const uint32_t lane_a = (uint32_t)(gl * 16 + h * 8), lane_b = (uint32_t)(gl * 16 + (1 - h) * 8);
     auto scatter = [&](const U4 &v, const uint32_t (&ew)[KQ]) {
 #pragma unroll
         for (int q = 0; q < KQ; q++) {
@@ -865,13 +879,13 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
             uint32_t gm = (uint32_t)(__ballot(ew[q] != 0xFFFFFFFFu) >> gbase) & (uint32_t)((1ull << LPR) - 1ull);
             while (__any(gm != 0)) {
                 const bool go = gm != 0;
-                const int u = go ? (__ffs((int)gm) - 1) : 0;
+                const int u = __builtin_ctz(gm);   // (gm == 0: any value -- such lanes read some lane and drop what they get)
                 gm &= gm - 1u;
-                const uint32_t ed = (uint32_t)__shfl((int)ew[q], gbase + u);
+                const uint32_t ed = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + u) << 2, (int)ew[q]);
                 if (go) {
-                    const uint32_t s = ed & 0xFFFFu, c = (ed >> 16) & 0xFFu;
-                    const U4 prod = gfmul16(lds_multab(mt, c), v);
-                    lds_xor16(acc + (size_t)s * B + gl * 16, prod, h);
+                    const U4 prod = gfmul16(lds_multab(mt, ed >> 24), v);
+                    const uint32_t ao = ed & 0x00FFFFFFu;
+                    lds_xor16_at(ao | lane_a, ao | lane_b, prod, h);   // (the accumulators start the LDS: lds_acc == 0, no static LDS)
                 }
             }
         }
@@ -880,13 +894,17 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     // A symbol's column-list word (check | coef << 16) becomes (slot | coef << 16) if the check is used by a step of
     // this frame -- other than the step that solves the symbol itself (own) -- and 0xFFFFFFFF otherwise: one LDS
     // look-up per lane, no per-frame lists in HBM.
+    // The entry leaves as (byte offset of the step's accumulator slice | coef << 24), what the turns of `scatter` consume.
     auto to_slots = [&](uint32_t (&ew)[KQ], uint32_t own) {
-        if (!translate) return;
 #pragma unroll
         for (int q = 0; q < KQ; q++) {
             const uint32_t w = ew[q];
+            if (!translate) {   // encoder: the static lists hold (slot | coef << 16) already
+                ew[q] = (w != 0xFFFFFFFFu) ? (((w & 0xFFFFu) * (uint32_t)B) | ((w & 0x00FF0000u) << 8)) : 0xFFFFFFFFu;
+                continue;
+            }
             const uint32_t s = soc[w == 0xFFFFFFFFu ? 0u : (w & 0xFFFFu)];
-            ew[q] = (w != 0xFFFFFFFFu && s != 0xFFFFu && s != own) ? (s | (w & 0x00FF0000u)) : 0xFFFFFFFFu;
+            ew[q] = (w != 0xFFFFFFFFu && s != 0xFFFFu && s != own) ? ((s * (uint32_t)B) | ((w & 0x00FF0000u) << 8)) : 0xFFFFFFFFu;
         }
     };
 
@@ -1389,7 +1407,7 @@ static ScatterPlan plan_scatter(const DevCode &cd, int S)
 static void scatter_set_lds(ScatterArgs &sa, const ScatterPlan &p, int nacc)
 {
     const int base = align_up(nacc * 16 * p.lpr, 16);
-    sa.lds_acc = 0;
+    sa.lds_acc = 0;   // (the streaming loop relies on it: accumulator offsets are used as LDS addresses)
     sa.lds_tgt = base + p.o_tgt; sa.lds_invc = base + p.o_invc; sa.lds_lvlend = base + p.o_lvl;
     sa.lds_rowctr = base + p.o_ctr; sa.lds_mt = base + p.o_mt; sa.lds_soc = base + p.o_soc; sa.lds_chk = base + p.o_chk;
     sa.lds_soc_bytes = p.soc_bytes;
