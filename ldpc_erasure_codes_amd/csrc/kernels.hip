@@ -861,8 +861,10 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     const uint8_t *fin0 = a.sym + f * (int64_t)a.in_rows * S + (int64_t)sl * B;
     uint8_t *fout0 = a.out + f * (int64_t)n * S + (int64_t)sl * B;
     const uint32_t lo16 = (uint32_t)gl * 16u, S32 = (uint32_t)S;
-    auto in_row = [&](int j) { return fin0 + ((uint32_t)j * S32 + lo16); };
-    auto out_row = [&](int j) { return fout0 + ((uint32_t)j * S32 + lo16); };
+    // (24-bit multiply: full rate, where the 32-bit one the compiler picked -- v_mad_u64_u32 -- runs at a quarter; j < 2^16 and
+    // S < 2^24 are checked by the host's plan)
+    auto in_row = [&](int j) { return fin0 + (__umul24((uint32_t)j, S32) + lo16); };
+    auto out_row = [&](int j) { return fout0 + (__umul24((uint32_t)j, S32) + lo16); };
     // H's static column lists (check | coef << 16); the encoder's are already in (slot | coef << 16) form
     const uint32_t *spad = a.static_sched ? cd.enc_src : cd.cell;
     const bool translate = !a.static_sched;
@@ -1376,7 +1378,7 @@ static int scatter_tail_bytes(const DevCode &cd, ScatterPlan &p)
 static ScatterPlan plan_scatter(const DevCode &cd, int S)
 {
     ScatterPlan p;
-    if ((uint64_t)cd.n * (uint64_t)S >= (1ull << 32)) return p;   // the kernel addresses a frame with 32-bit offsets
+    if ((uint64_t)cd.n * (uint64_t)S >= (1ull << 32) || S >= (1 << 24) || cd.n >= (1 << 16)) return p;   // the kernel addresses a frame with 32-bit offsets (24-bit multiplies)
     int B = 256;
     const char *env_b = getenv("LDPC_AMD_SCATTER_B");  // A/B knob: bytes of every row per workgroup
     if (env_b && (atoi(env_b) == 128 || atoi(env_b) == 64)) B = atoi(env_b);
