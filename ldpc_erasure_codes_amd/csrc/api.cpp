@@ -281,7 +281,7 @@ static int register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_pt
             for (uint32_t e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
                 const int j = cols[e];
                 if (j == k + r) continue;
-                enc_src[((size_t)j << cdw_shift) + fillc[j]++] = slot_of_row[r] | ((uint32_t)hc->coefs[e] << 16);
+                enc_src[((size_t)j << cdw_shift) + fillc[j]++] = ((uint32_t)slot_of_row[r] * 128u) | ((uint32_t)hc->coefs[e] << 24);
             }
     }
     // encoder: source rows in the order of their column degree (every check is a step of the static schedule, so a row's

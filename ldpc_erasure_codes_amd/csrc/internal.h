@@ -53,7 +53,7 @@ struct DevCode {
     const uint32_t *enc_steps;   // [m] row | (k+row) << 16
     const uint16_t *enc_lvlend;  // [enc_nlevels+1], [L] = end offset of level L, [0] = 0
     int enc_nlevels;
-    const uint32_t *enc_src;     // [n][1 << cdw_shift] static symbol -> (slot | coef << 16) lists of the encoder
+    const uint32_t *enc_src;     // [n][1 << cdw_shift] static symbol -> (slot * 128 | coef << 24) lists of the encoder (LDS offset of the slot's 128-byte piece)
     const uint16_t *enc_order;   // [k] source symbols ordered by the number of checks they feed (most first; index order within)
 };
 

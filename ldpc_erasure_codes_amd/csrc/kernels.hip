@@ -872,7 +872,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     // multiplies v into the accumulators of the steps that symbol j feeds: ew = the symbol's list, entry t held by
     // lane (t % LPR) of the group, 0xFFFFFFFF = no entry.  Every group walks the set bits of its own validity mask.
     // (entries are in the form to_slots leaves them in: accumulator byte offset | coef << 24; a lane's own 16 bytes of the
-    // accumulator, halves in the bank-friendly order, are OR-ed in: the offset's low bits are free, B >= 64)
+    // accumulator, halves in the bank-friendly order, are OR-ed in: the offset is a multiple of B, the lane's part is below B)
     const uint32_t lane_a = (uint32_t)(gl * 16 + h * 8), lane_b = (uint32_t)(gl * 16 + (1 - h) * 8);
     auto scatter = [&](const U4 &v, const uint32_t (&ew)[KQ]) {
 #pragma unroll
@@ -901,8 +901,9 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
 #pragma unroll
         for (int q = 0; q < KQ; q++) {
             const uint32_t w = ew[q];
-            if (!translate) {   // encoder: the static lists hold (slot | coef << 16) already
-                ew[q] = (w != 0xFFFFFFFFu) ? (((w & 0xFFFFu) * (uint32_t)B) | ((w & 0x00FF0000u) << 8)) : 0xFFFFFFFFu;
+            if (!translate) {   // encoder: the static lists hold (slot * 128 | coef << 24): the form of its default 128-byte pieces
+                if (B > 128) ew[q] = (w != 0xFFFFFFFFu) ? (((w & 0x00FFFFFFu) * (uint32_t)(B / 128)) | (w & 0xFF000000u)) : 0xFFFFFFFFu;
+                else if (B < 128) ew[q] = (w != 0xFFFFFFFFu) ? (((w & 0x00FFFFFFu) / (uint32_t)(128 / B)) | (w & 0xFF000000u)) : 0xFFFFFFFFu;
                 continue;
             }
             const uint32_t s = soc[w == 0xFFFFFFFFu ? 0u : (w & 0xFFFFu)];
