@@ -1665,10 +1665,13 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         int grid = (int)std::min<int64_t>(nf, (int64_t)ctx->sm_count);
         const size_t perA = (size_t)cd.m * maxrow, perR = fused ? 0 : (size_t)cd.m * d.S;
         if ((rc = scratch_reserve(ctx, ctx->mlws, (perA + perR) * grid + 256))) return rc;
-        ma.work = (int32_t *)ctx->mlws.p;                 // first 256 bytes: [0] frame hand-out counter, [2..3] arena bump
-        ma.wsA = (uint8_t *)ctx->mlws.p + 256;            // pointer (u64), [4] task counter of the solve kernel
+        // work counters: [0] frame hand-out counter, [2..3] arena bump pointer (u64), [4] task counter of the solve kernel.  They
+        // sit in the free tail of the residual list's header (ints 18..23), which launch_decode zeroes with that header: one
+        // memset per call less (a call is launch-bound at S = 1)
+        static_assert(kMlHdr >= 18 + 6 && 1 + kMlClasses <= 18, "ml_list header: no room for the work counters");
+        ma.work = (int32_t *)ctx->mllist.p + 18;
+        ma.wsA = (uint8_t *)ctx->mlws.p + 256;
         ma.wsR = ma.wsA + perA * grid;
-        LDPC_HIP_TRY(ctx, hipMemsetAsync(ma.work, 0, 32, ctx->stream));
         // packets: the ML kernel factors every residual system on bytes and emits a solve schedule (64-bit ops grouped by
         // dependency level) into an arena; ldpc_ml_solve_kernel then runs the schedules on LDS-resident row slices.
         // Frames whose schedule does not fit the arena are solved inside the ML kernel (same bytes, slower).
