@@ -2,7 +2,7 @@
 """A/B of two BUILDS of the library on one box (box-to-box spread is 3-5 %, more than most kernel changes are worth):
     python tools/ab_lib.py old.so new.so [--rounds 3]
 Every round starts one child process per library, alternating; a child times the packet kernel on the cfg 2 batch (plain and
-in place), the whole cfg 3 step at S = 1024 and the encoder, with the in-library HIP events.  Medians per library are printed."""
+in place), the cfg 3 step at S = 1024 and at S = 1 and the encoder, with the in-library HIP events.  Medians per library are printed."""
 import argparse
 import json
 import os
@@ -60,6 +60,14 @@ def child(so):
     res["cfg3_apply"], res["cfg3_ml"] = t["apply"], t["ml"]
     ok = st.cpu().numpy() <= 1
     assert torch.equal(out[torch.from_numpy(ok).to(g.dev)], cw[torch.from_numpy(ok).to(g.dev)])
+    del cw, sym, era, out
+    torch.cuda.empty_cache()
+    cw, sym, era, _ = g.make_batch("cfg3", 1, 1, frame0=0, nframes=4096)
+    out = torch.empty_like(sym)
+    st = torch.empty(sym.shape[0], dtype=torch.int32, device=g.dev)
+    res["cfg3_s1_ml"] = timed(lambda: ctx.decode(h, sym, era, out=out, status=st), ["ml"], reps=10)["ml"]
+    ok = torch.from_numpy(st.cpu().numpy() <= 1).to(g.dev)
+    assert torch.equal(out[ok], cw[ok])
     print(json.dumps(res))
 
 
