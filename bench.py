@@ -47,13 +47,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s; ~6.3 TB/s achievable)
 SEED_SRC, SEED_ERA = 20261004, 20261005
 GE_PARAMS = (0.13, 0.8, 10.0)   # cfg 3: alpha, beta, good_transition_bias -- ML stage on ~28 % of the frames
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "round2_pmc_summary.json")
+# PMC summaries (separate rocprofv3 --pmc passes of this same command, committed): newest first
+PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in
+                 ("round3_pmc_summary.json", "round3_cfg4p_pmc_summary.json", "round2_pmc_summary.json")]
 
 # BASELINE.json configs -> (code_ind, channel, frames)
 WORKLOADS = {
     "cfg2": dict(code=1, channel=("uniform", 0.10), frames=4096),
     "cfg3": dict(code=1, channel=("bursty",) + GE_PARAMS, frames=4096),
     "cfg4": dict(code=3, channel=("uniform", 0.10), frames=65536, rs=(255, 223)),
+    # cfg 4's code on the packet (HBM-roofline) path: 65536 frames x 4080 x 1 KB x 2 would be 548 GB, so the packet run takes
+    # the first 4096 frames of the same stream (34 GB in + out)
+    "cfg4p": dict(code=3, channel=("uniform", 0.10), frames=4096),
     "cfg5": dict(codes=(2, 1), channel=("uniform", 0.10), frames=65536),
 }
 
@@ -68,23 +73,28 @@ def rs_alg_bytes_per_block(k, S):
     return 2 * k * S + 2 * k
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate --pmc FETCH_SIZE / WRITE_SIZE
-    passes of this same command, gfx950 correction applied: tools/summarize_profiles.py).  The counters cannot be read from
-    inside this process; a launch plan the summary does not know gets a warning, not a silent null."""
-    if not os.path.exists(PMC_SUMMARY):
-        print(f"bench.py: no PMC summary at {PMC_SUMMARY}: roofline.traffic = null", file=sys.stderr)
-        return None
-    try:
-        ks = json.load(open(PMC_SUMMARY))["kernels"]
-    except (KeyError, ValueError):
-        print(f"bench.py: {PMC_SUMMARY} is not a PMC summary: roofline.traffic = null", file=sys.stderr)
-        return None
-    if kernel not in ks:
-        print(f"bench.py: PMC summary has no entry for the launched kernel '{kernel}' (has: {sorted(ks)}): "
-              "roofline.traffic = null -- re-run the --pmc passes for this launch plan", file=sys.stderr)
-        return None
-    return ks[kernel].get("traffic_bytes")
+def pmc_traffic(kernel, workload="cfg2"):
+    """(HBM bytes per launch of `kernel`, source file) from the committed rocprofv3 PMC summaries (separate --pmc FETCH_SIZE /
+    WRITE_SIZE passes of this same command, gfx950 correction applied: tools/summarize_profiles.py).  The counters cannot be
+    read from inside this process, so the figure is REPLAYED from the committed file of the same workload and kernel name (the
+    line says which: roofline.traffic_source); a launch plan no summary knows gets a warning, not a silent null."""
+    seen = []
+    for path in PMC_SUMMARIES:
+        if not os.path.exists(path):
+            continue
+        try:
+            doc = json.load(open(path))
+            ks = doc["kernels"]
+        except (KeyError, ValueError):
+            continue
+        if doc.get("workload", "cfg2") != workload:
+            continue
+        seen += sorted(ks)
+        if kernel in ks and ks[kernel].get("traffic_bytes") is not None:
+            return ks[kernel]["traffic_bytes"], os.path.relpath(path, ROOT) + " (replayed: separate --pmc passes of this command)"
+    print(f"bench.py: no committed PMC summary of workload {workload} has the launched kernel '{kernel}' (have: {seen}): "
+          "roofline.traffic = null -- re-run the --pmc passes for this launch plan", file=sys.stderr)
+    return None, None
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -183,8 +193,10 @@ def cpu_model():
 
 def cpu_baseline(cfg, S, seconds):
     """single_thread (one worker) and all_cores (one worker per core of this process's affinity mask)."""
-    cores_total = len(os.sched_getaffinity(0))
-    out = {"unit": "frames/s", "kind": "port", "cores_total": cores_total, "cpu_model": cpu_model()}
+    cores_total = len(os.sched_getaffinity(0))   # hardware THREADS of the affinity mask (SMT siblings count)
+    out = {"unit": "frames/s", "kind": "port", "threads_total": cores_total, "cores_total": cores_total,
+           "cores_total_note": "hardware threads of this process's affinity mask (SMT siblings included), one worker each",
+           "cpu_model": cpu_model()}
     for label, nw in (("single_thread", 1), ("all_cores", min(cores_total, 256))):
         t0 = time.perf_counter()
         with mp.get_context("fork").Pool(nw) as pool:
@@ -194,6 +206,9 @@ def cpu_baseline(cfg, S, seconds):
         out[label] = rate
         frames = sum(r[0] for r in res)
         if label == "all_cores":
+            if S >= 256 and out.get("single_thread"):
+                out["all_cores_note"] = (f"{rate / out['single_thread']:.1f}x one thread on {nw} threads: at S={S} every worker streams "
+                                         "MBs per frame, so the all-threads leg is bound by host memory bandwidth, not by cores")
             out.update({"value": rate, "cores": nw,
                         "sample": f"{frames} frames of the GPU's own batch ({cfg}, S={S}) decoded by oracle/oracle.c, "
                                   f"~{seconds:g} s of decode time per worker on {nw} workers ({wall:.1f} s wall incl. input "
@@ -412,8 +427,9 @@ def run_cfg2(g, args):
             # nominal HBM peak; bytes moved = read + write
             copy_ms = g.ctx.copy_probe(sym, r["out"], reps=5)
             copy_gbps = 2.0 * sym.numel() / (copy_ms * 1e-3) / 1e9
+        traffic, tsrc = pmc_traffic(r["names"][kind]) if F == 4096 else (None, None)
         s["roofline"] = {"bound": "hbm", "kernel": r["names"][kind], "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBPS, "traffic": pmc_traffic(r["names"][kind]) if F == 4096 else None,
+                         "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": tsrc,
                          "alg_bytes_per_launch": ab, "avg_launch_ms": kavg, "copy_kernel_GBps": copy_gbps,
                          "frac_of_copy": (ach / copy_gbps) if copy_gbps else None}
         s["sustained"] = None
@@ -430,6 +446,24 @@ def run_cfg2(g, args):
             dts = sharding.max_over_ranks(time.perf_counter() - t1, g.dev)
             s["sustained"] = {"steps": n_sus, "seconds": dts, "ms_per_step": dts / n_sus * 1e3, "frames_per_s": g.world * F * n_sus / dts,
                               "verified": bool(torch.equal(out2, cw))}
+        s["xgmi_probe"] = None
+        if S == args.S and g.world > 1 and g.backend == "nccl":
+            # not part of `value`: one RCCL all-gather of a 64 MB slice of the decoded output per rank, so that a multi-GPU run
+            # of the default command also yields an xGMI figure (the job's own collective moves only 12 B per frame)
+            nb = min(64 << 20, r["out"].numel())
+            piece = r["out"].reshape(-1)[:nb]
+            flat = torch.empty(g.world * nb, dtype=torch.uint8, device=g.dev)
+            g.dist.all_gather_into_tensor(flat, piece)
+            g.barrier()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                g.dist.all_gather_into_tensor(flat, piece)
+            g.barrier()
+            dtg = sharding.max_over_ranks((time.perf_counter() - t1) / 3, g.dev)
+            s["xgmi_probe"] = {"collective": "all_gather_into_tensor", "bytes_per_rank": nb, "ms": dtg * 1e3,
+                               "recv_GBps_per_rank": (g.world - 1) * nb / dtg / 1e9,
+                               "verified": bool(torch.equal(flat[g.rank * nb:(g.rank + 1) * nb], piece))}
+            del flat
         s["inplace"] = None
         if S >= 16 and g.world == 1:
             # extension, reported separately and never as `value`: LDPC_AMD_INPLACE decodes inside the caller's frame buffer
@@ -464,9 +498,9 @@ def run_cfg3(g, args, S):
     steps = max(3, min(args.steps, 10))
     r = g.time_decode(h, sym, era, steps, min(args.warmup, 2))
     s = summarize(g, r, cw, n, k, S, steps, cw.shape[0])
-    s["workload"] = (f"BASELINE cfg3: (2040,1530) hybrid MP+ML, Gilbert-Elliott alpha={GE_PARAMS[0]} beta={GE_PARAMS[1]} "
+    s["workload"] = (f"S={S} bytes/symbol, BASELINE cfg3: (2040,1530) hybrid MP+ML, Gilbert-Elliott alpha={GE_PARAMS[0]} beta={GE_PARAMS[1]} "
                      f"bias={GE_PARAMS[2]:g} (chain carried across frames), {WORKLOADS['cfg3']['frames']} frames drawn, "
-                     f"{cw.shape[0]} with E0 < n-k decoded (the rest skipped as in ErasureCodes_NonBinaryLDPCSim.m:216), S={S}")
+                     f"{cw.shape[0]} with E0 < n-k decoded (the rest skipped as in ErasureCodes_NonBinaryLDPCSim.m:216)")
     s["frames_skipped_E0_ge_m"] = int((~keep).sum())
     s["sample"] = pick_samples(r, sym, era, True)
     del cw, sym, era, r
@@ -487,8 +521,8 @@ def run_cfg4(g, args):
     steps = 3
     r = g.time_decode(h, sym, era, steps, 1)
     s = summarize(g, r, cw, n, k, 1, steps, F)
-    s["workload"] = ("BASELINE cfg4: (4080,3060) GF(256) LDPC [matrix synthesised by tools/hgen.cpp -- the reference names the "
-                     "code but does not ship it] vs 16 x RS(255,223) on the same erasure patterns, 65536 frames, uniform 10 %, S=1")
+    s["workload"] = ("S=1 byte/symbol, BASELINE cfg4: (4080,3060) GF(256) LDPC [matrix synthesised by tools/hgen.cpp -- the reference "
+                     "names the code but does not ship it] vs 16 x RS(255,223) on the same erasure patterns, 65536 frames, uniform 10 %")
     s["sample"] = pick_samples(r, sym, era, False)
     rn, rk = WORKLOADS["cfg4"]["rs"]
     rs = ctx.rs_create(rn, rk)
@@ -524,7 +558,81 @@ def run_cfg4(g, args):
     return {"ldpc": s, "rs": s_rs}
 
 
-def run_cfg5(g, args, total, gather):
+def run_cfg4_packets(g, args, S=1024):
+    """(4080,3060) on the packet (HBM-roofline) path -- north_star names this matrix next to (2040,1530) -- and RS(255,223)
+    in packet mode (the paper's system model: S RS codecs in parallel, Latex/Milcom_2022_ErasureCodes.tex:53,125) on the
+    erasure patterns of the same frames.  4096 frames (the first 4096 of cfg 4's stream): 65536 x 4080 x 1 KB does not fit."""
+    torch, ctx = g.torch, g.ctx
+    from ldpc_erasure_codes_amd import codes
+    if not codes.have_builtin(3):
+        return None
+    h, n, k = g.code(3)
+    F = WORKLOADS["cfg4p"]["frames"]
+    cw, sym, era, _ = g.make_batch("cfg4p", 3, S, frame0=0, nframes=F)
+    steps = max(3, min(args.steps, 10))
+    r = g.time_decode(h, sym, era, steps, 2)
+    s = summarize(g, r, cw, n, k, S, steps, F)
+    s["workload"] = (f"S={S} bytes/symbol, BASELINE cfg4's code on the packet path: (4080,3060) GF(256) LDPC [matrix synthesised by "
+                     f"tools/hgen.cpp -- the reference names the code but does not ship it], uniform 10 %, {F} frames "
+                     f"(= {2 * F * n * S / 1e9:.1f} GB in + out; 65536 frames x 1 KB packets would be 548 GB)")
+    s["verified"] = s["verified"] and int(r["st"].max()) == 0
+    kavg = r["kernel_ms"]["apply"]
+    ab = alg_bytes_per_frame(n, S) * F
+    ach = ab / (kavg * 1e-3) / 1e9 if kavg > 0 else 0.0
+    traffic, tsrc = pmc_traffic(r["names"]["apply"], "cfg4p")
+    s["roofline"] = {"bound": "hbm", "kernel": r["names"]["apply"], "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": tsrc,
+                     "alg_bytes_per_launch": ab, "avg_launch_ms": kavg}
+    s["plan"] = ctx.last_plan()
+    s["S"] = S
+    s["sample"] = pick_samples(r, sym, era, False)
+    del cw, sym, r
+    torch.cuda.empty_cache()
+
+    # ---- RS(255,223), S-byte packets, on the same erasure patterns (block i = symbols 255 i ... 255 i + 254)
+    rn, rk = WORKLOADS["cfg4"]["rs"]
+    rs = ctx.rs_create(rn, rk)
+    blocks = era.reshape(F * (n // rn), rn)
+    received = blocks == 0
+    can = received.sum(dim=1) >= rk
+    order = torch.argsort((~received).to(torch.uint8), dim=1, stable=True)[:, :rk]
+    sel = torch.nonzero(can).flatten()
+    B = int(sel.numel())
+    rsrc = torch.empty((B, rk, S), dtype=torch.uint8, device=g.dev)
+    ctx.synth_source(SEED_SRC + 78, 0, B, rk, S, rsrc)
+    rcw = ctx.rs_encode(rs, rn, rk, rsrc)
+    idx = order[sel].to(torch.int16).contiguous()
+    val = rcw[torch.arange(B, device=g.dev)[:, None], order[sel]].contiguous()
+    del rcw
+    msg = ctx.rs_decode(rs, idx, val)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        msg = ctx.rs_decode(rs, idx, val, out=msg)
+    ev1.record()
+    torch.cuda.synchronize()
+    trs = (time.perf_counter() - t0) / steps
+    kms = ev0.elapsed_time(ev1) / steps
+    rs_ab = rs_alg_bytes_per_block(rk, S) * B
+    missing = (order[sel] >= rk).sum(dim=1).float()   # received repair symbols among the first k = missing source symbols
+    s_rs = {"workload": f"S={S} bytes/symbol, RS(255,223) erasure decode of the {B} decodable blocks (of {F * (n // rn)}: 16 per frame "
+                        f"pattern, uniform 10 %), k*S in + 2k + k*S out = {rs_alg_bytes_per_block(rk, S)} algorithmic bytes per block",
+            "blocks_total": F * (n // rn), "blocks_decodable": B, "blocks_per_s": B / trs, "ms_per_step": trs * 1e3,
+            "kernel_ms": {"rs_decode": kms}, "frame_equivalents_per_s": B / (n // rn) / trs,
+            "recovered_GBps": B / trs * rk * S / 1e9, "mean_missing_source_symbols": float(missing.mean()),
+            "gf_macs_per_block_row": float((missing * rk).mean()),
+            "alg_bytes_per_step": rs_ab, "roofline_frac": rs_ab / (kms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "verified": bool(torch.equal(msg, rsrc)), "block_failure_rate": 1.0 - B / float(F * (n // rn))}
+    # oracle spot check of two blocks (after the timed region)
+    s_rs["sample"] = (idx[:2].cpu().numpy().astype(np.uint16), val[:2].cpu().numpy(), msg[:2].cpu().numpy())
+    del era, idx, val, order, msg, rsrc
+    torch.cuda.empty_cache()
+    return {"ldpc": s, "rs": s_rs}
+
+
+def run_cfg5(g, args, total, gather, S=1):
     """Mixed (4000,2000) + (2040,1530) stream, 1:1, sharded over the ranks: bucket by code, each rank decodes its block of
     every bucket, then ONE gather (status words, or outputs + status words).  Decode and gather are timed separately."""
     torch = g.torch
@@ -534,7 +642,7 @@ def run_cfg5(g, args, total, gather):
     mine = sharding.shard_mixed(ids, g.rank, g.world)
     batches = {}
     for ci, gidx in mine.items():
-        cw, sym, era, keep = g.make_batch("cfg5", ci, 1, frame_ids=gidx)
+        cw, sym, era, keep = g.make_batch("cfg5", ci, S, frame_ids=gidx)
         assert bool(keep.all())
         F = sym.shape[0]
         batches[ci] = dict(cw=cw, sym=sym, era=era, out=torch.empty_like(sym),
@@ -563,13 +671,14 @@ def run_cfg5(g, args, total, gather):
     ok = all(bool(torch.equal(b["out"], b["cw"])) and int(b["st"].max()) == 0 for b in batches.values() if b["sym"].shape[0])
     gathered_frames = sum(int(v["words"].shape[1]) for v in full.values())
     gbytes = sum(int(v["words"].numel()) * 4 + (int(v["out"].numel()) if v["out"] is not None else 0) for v in full.values())
-    ab = sum(alg_bytes_per_frame(handles[ci][1], 1) * int((ids == ci).sum()) for ci in handles)
+    ab = sum(alg_bytes_per_frame(handles[ci][1], S) * int((ids == ci).sum()) for ci in handles)
     per_step = (dt_dec / steps) + dt_gat          # one job = decode the stream once + the final gather
-    s = {"workload": f"BASELINE cfg5: mixed (4000,2000) + (2040,1530) stream 1:1, uniform 10 %, {total} frames over {g.world} "
-                     f"GPU(s) (bucketed by code, contiguous blocks per rank), S=1, final gather of {gather}",
+    s = {"workload": f"S={S} bytes/symbol, BASELINE cfg5: mixed (4000,2000) + (2040,1530) stream 1:1, uniform 10 %, {total} frames over "
+                     f"{g.world} GPU(s) (bucketed by code, contiguous blocks per rank), final gather of {gather}",
+         "S": S,
          "frames": total, "frames_this_rank": sum(b["sym"].shape[0] for b in batches.values()),
          "frames_per_s": total / per_step, "decode_ms_per_step": dt_dec / steps * 1e3, "gather_ms": dt_gat * 1e3,
-         "gather": gather, "gathered_frames": gathered_frames, "gathered_bytes_per_rank": gbytes,
+         "gather": gather, "gathered_frames": gathered_frames, "gathered_bytes": gbytes, "gathered_bytes_per_rank": gbytes,
          "gather_GBps_per_rank": gbytes / dt_gat / 1e9 if dt_gat > 0 else None,
          "alg_bytes_per_step": ab, "roofline_frac": ab / (dt_dec / steps) / 1e9 / HBM_PEAK_GBPS / g.world,
          "steps": steps, "verified": ok and gathered_frames == total}
@@ -596,6 +705,7 @@ def main():
                          "(5 = the 65536-frame mixed stream sharded over --gpus ranks)")
     ap.add_argument("--gather", default="status", choices=["status", "outputs"], help="cfg 5: what the final gather moves")
     ap.add_argument("--total-frames", type=int, default=None, help="cfg 5: frames of the whole stream (default 65536)")
+    ap.add_argument("--cfg5-S", type=int, default=1, help="cfg 5 alone (--config 5): bytes per symbol (e.g. 64 with --gather outputs)")
     ap.add_argument("--cpu-seconds", type=float, default=3.0, help="CPU-baseline decode time per worker and leg")
     ap.add_argument("--sustain-seconds", type=float, default=5.0,
                     help="after the timed K steps, repeat the headline step for about this long and report it as `sustained` (0: off)")
@@ -635,6 +745,7 @@ def main():
                 side_leg("cfg3", S_)
         if want_block or args.config == "4":
             side_leg("cfg4", 1)
+            side_leg("cfg4p", 1024)
         if want_block or args.config == "5":
             side_leg("cfg5", 1)
 
@@ -657,15 +768,21 @@ def main():
             for S in (1024, 1):
                 side(f"cfg3_S{S}", lambda S=S: run_cfg3(g, args, S))
             side("cfg4", lambda: run_cfg4(g, args))
-            side("cfg5", lambda: run_cfg5(g, args, WORKLOADS["cfg5"]["frames"] // 8, args.gather))
+            side("cfg4_S1024", lambda: run_cfg4_packets(g, args))
+            # the WHOLE 65536-frame stream on one GPU (the N = 1 anchor of the strong-scaling job) and one GPU's 1/8 share
+            side("cfg5", lambda: run_cfg5(g, args, WORKLOADS["cfg5"]["frames"], args.gather))
+            side("cfg5_one_eighth", lambda: run_cfg5(g, args, WORKLOADS["cfg5"]["frames"] // 8, args.gather))
             if "cfg5" in block:
-                block["cfg5"]["workload"] += " -- ONE GPU's share (1/8) of the 8-GPU job; `--config 5 --gpus 8` runs the whole stream"
+                block["cfg5"]["workload"] += " -- the whole stream on ONE GPU: the N = 1 anchor of `--config 5 --gpus N` (strong scaling)"
+            if "cfg5_one_eighth" in block:
+                block["cfg5_one_eighth"]["workload"] += " -- ONE GPU's share (1/8) of the 8-GPU job"
+            side("cfg5_S64_outputs", lambda: run_cfg5(g, args, 8192, "outputs", S=64))
     elif args.config == "3":
         block = {f"cfg3_S{S}": run_cfg3(g, args, S) for S in sorted({args.S} if args.no_s1 else {args.S, 1}, reverse=True)}
     elif args.config == "4":
-        block = {"cfg4": run_cfg4(g, args)}
+        block = {"cfg4": run_cfg4(g, args)} if args.S == 1 else {"cfg4_S1024": run_cfg4_packets(g, args, args.S)}
     else:
-        block = {"cfg5": run_cfg5(g, args, args.total_frames or WORKLOADS["cfg5"]["frames"], args.gather)}
+        block = {"cfg5": run_cfg5(g, args, args.total_frames or WORKLOADS["cfg5"]["frames"], args.gather, S=args.cfg5_S)}
     g.close()
     if rank != 0:
         return
@@ -690,18 +807,32 @@ def main():
         elif name == "cfg4" and e:
             check(e["ldpc"], 3, 1)
             key = ("cfg4", 1)
-        elif name == "cfg5":
+        elif name == "cfg4_S1024" and e:
+            check(e["ldpc"], 3, e["ldpc"]["S"])
+            from oracle import oracle_py
+            rn, rk = WORKLOADS["cfg4"]["rs"]
+            rs_g = oracle_py.rs_generator(rn, rk)
+            ix, vv, mm = e["rs"].pop("sample")
+            ok = True
+            for b in range(ix.shape[0]):
+                for lane in (0, vv.shape[2] // 2, vv.shape[2] - 1):   # three byte lanes of the packet, each an S = 1 decode
+                    om, _ = oracle_py.rs_decode(rs_g, ix[b], np.ascontiguousarray(vv[b, :, lane]))
+                    ok = ok and bool(np.array_equal(om, mm[b, :, lane]))
+            e["rs"]["verified"] = bool(e["rs"]["verified"] and ok)
+            e["rs"]["oracle_spot_check_blocks"] = int(ix.shape[0])
+            key = ("cfg4p", 1024)
+        elif name.startswith("cfg5"):
             for ci, smp in e.pop("samples").items():
-                ok, cnt = oracle_check(ci, 1, smp)
+                ok, cnt = oracle_check(ci, e.get("S", 1), smp)
                 e["verified"] = bool(e["verified"] and ok)
-            key = ("cfg5", 1)
+            key = ("cfg5", 1) if e.get("S", 1) == 1 else None
         else:
             continue
         if key in cpu:
             cb = cpu[key]
-            tgt = e["ldpc"] if name == "cfg4" else e
+            tgt = e["ldpc"] if name in ("cfg4", "cfg4_S1024") else e
             tgt["cpu_baseline"] = cb
-            if name != "cfg5" or world == 1:
+            if not name.startswith("cfg5") or world == 1:
                 tgt["gpu_over_cpu_all_cores"] = tgt["frames_per_s"] / cb["value"] if cb.get("value") else None
             if name == "cfg4" and cb.get("rs_blocks_per_s"):
                 e["rs"]["gpu_over_cpu_all_cores"] = e["rs"]["blocks_per_s"] / cb["rs_blocks_per_s"]
@@ -714,8 +845,8 @@ def main():
             "value": main_r["frames_per_s"], "unit": "frames/s", "recovered_GBps": main_r["recovered_GBps"],
             "n_gpus": world, "steps": main_r["steps"], "warmup": args.warmup, "ms_per_step": main_r["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"BASELINE cfg2: n=2040,k=1530 GF(256) LDPC (H_nb seed {2040}), 10% uniform random erasures, "
-                                   f"batch={args.frames} frames per GPU, S={args.S} bytes/symbol, max_sweeps=10, ML on",
+            "config": {"workload": f"S={args.S} bytes/symbol, BASELINE cfg2: n=2040,k=1530 GF(256) LDPC (H_nb seed {2040}), 10% uniform "
+                                   f"random erasures, batch={args.frames} frames per GPU, max_sweeps=10, ML on",
                        "frames_per_gpu": args.frames, "S": args.S, "per": 0.10, "code": "n2040_k1530",
                        "sharding": f"{world} x {args.frames} independent frames, status gather over RCCL"},
             "verified_bit_exact": main_r["verified"], "sweeps_hist": main_r["sweeps_hist"],
@@ -724,6 +855,8 @@ def main():
         }
         if main_r.get("sustained"):
             line["sustained"] = main_r["sustained"]
+        if main_r.get("xgmi_probe"):
+            line["xgmi_allgather_probe"] = main_r["xgmi_probe"]
         if main_r.get("inplace"):
             ip = main_r["inplace"]
             ach_ip = alg_bytes_per_frame(n, args.S) * args.frames / (ip["kernel_ms"]["apply"] * 1e-3) / 1e9

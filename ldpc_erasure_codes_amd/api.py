@@ -321,18 +321,18 @@ class Context:
                     "rs_encode_batch")
         return out
 
-    def rs_decode(self, rs, recv_idx, recv_val):
+    def rs_decode(self, rs, recv_idx, recv_val, out=None):
         """recv_idx [B,k] uint16 (0-based ascending), recv_val [B,k,S] or [B,k] -> msg like recv_val."""
         dev = _is_torch(recv_val)
         B = recv_val.shape[0]
         S = 1 if recv_val.ndim == 2 else recv_val.shape[2]
         if dev:
             import torch
-            msg = torch.empty_like(recv_val)
+            msg = torch.empty_like(recv_val) if out is None else out
         else:
             recv_idx = np.ascontiguousarray(recv_idx, dtype=np.uint16)
             recv_val = np.ascontiguousarray(recv_val, dtype=np.uint8)
-            msg = np.empty_like(recv_val)
+            msg = np.empty_like(recv_val) if out is None else out
         self._check(self._L.ldpc_amd_rs_decode_batch(self._h, rs, S, B, _ptr(recv_idx), _ptr(recv_val), _ptr(msg),
                                                      DEVICE_PTRS if dev else 0), "rs_decode_batch")
         return msg

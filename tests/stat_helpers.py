@@ -15,7 +15,7 @@ def two_sample_pvalue(x, n, y, m):
     return min(1.0, 2.0 * min(lo, hi))
 
 
-def consistent_with_reported(x, n, rate_lo, rate_hi, m, alpha=1e-4):
+def consistent_with_reported(x, n, rate_lo, rate_hi, m, alpha=1e-3):
     """x errors in n trials here; the paper reports a rate in [rate_lo, rate_hi] (its rounding) measured on m trials.
     True if some error count of the paper inside that interval passes the two-sample test at level alpha."""
     y_lo, y_hi = int(round(rate_lo * m)), int(round(rate_hi * m))
@@ -26,7 +26,7 @@ def consistent_with_reported(x, n, rate_lo, rate_hi, m, alpha=1e-4):
     return best >= alpha, best
 
 
-def consistent_with_rate(x, n, rate, alpha=1e-4):
+def consistent_with_rate(x, n, rate, alpha=1e-3):
     """x errors in n trials against an exactly known rate (binomial, two-sided)."""
     lo = binom.cdf(x, n, rate)
     hi = binom.sf(x - 1, n, rate)

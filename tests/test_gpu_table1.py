@@ -76,7 +76,7 @@ def test_table1_row(ctx, code_ind, per64, nframes, ldpc_iv, rs_iv, paper_n):
     ok, pv = consistent_with_rate(rs_err, mult * nframes, exact)
     assert ok, f"RS BLER {rs_err}/{mult * nframes} vs exact tail {exact:.4g}: p = {pv:.2e}"
     # ... then the paper's own figure.  Row 11/64 of the paper (9.3e-4) is itself 2.5 sigma above the closed form (9.03e-4)
-    ok, pv = consistent_with_reported(rs_err, mult * nframes, rs_iv[0], rs_iv[1], mult * paper_n, alpha=1e-6)
+    ok, pv = consistent_with_reported(rs_err, mult * nframes, rs_iv[0], rs_iv[1], mult * paper_n, alpha=1e-3)
     assert ok, f"RS BLER {rs_err}/{mult * nframes} vs the paper's {rs_iv}: p = {pv:.2e}"
 
 
@@ -175,4 +175,37 @@ def test_paper_figure_bler_curves():
     assert mp[0.16] < rs[0.16] and mp[0.20] > rs[0.20] and 0.5 < mp[0.18] / rs[0.18] < 1.5   # the curves cross at 18 % (tex:164)
     assert rows[0.16]["ml"] == 0 and rows[0.18]["ml"] == 0                                   # MP + ML: no error observed
     assert all(rows[per]["ml"] / rows[per]["frames"] < rs[per] for per in rows)              # ... and below RS at all PERs (tex:164)
+    tctx.close()
+
+
+def test_paper_figure_code_c_qualitative():
+    """The paper's second BLER figure, Latex/LDPC_triangular_4080_3060_Perf_vs_RS.png (tex:164), for the (4080,3060) code.  The
+    reference does not ship that matrix: this runs the same experiment on the matrix SYNTHESISED by tools/hgen.cpp
+    with the reference's construction rules, so only the figure's qualitative statements are checkable: message passing alone
+    is better than the RS(255,192)-equivalent code at low PER and worse beyond a crossing near 18-20 %; the MP + ML decoder
+    is below RS at every PER ("outperforms the RS code at all PER's")."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import paper_figure
+    from ldpc_erasure_codes_amd import codes
+    if not codes.have_builtin(3):
+        pytest.skip("(4080,3060) not built in")
+    tctx = api.Context(0)
+    tctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    rows = {}
+    for per, nf in ((0.16, 250000), (0.18, 100000), (0.20, 20000), (0.22, 5000)):
+        r = paper_figure.run(tctx, torch, per, nf, seed=4080, code_ind=3, chunk=50000)
+        rows[per] = r
+        print(f"\nfigure (4080,3060) [synthesised matrix] PER {per:.2f}: MP {r['mp'] / nf:.3g}  MP+ML {r['ml'] / nf:.3g} "
+              f"({r['skipped']} skipped)  RS {r['rs'] / r['rs_blocks']:.3g}")
+        exact = binom.sf(63, 255, per)
+        ok, pv = consistent_with_rate(r["rs"], r["rs_blocks"], exact)
+        assert ok, f"RS-equivalent BLER at {per}: {r['rs']}/{r['rs_blocks']} vs {exact:.4g} (p = {pv:.2e})"
+    mp = {per: rows[per]["mp"] / rows[per]["frames"] for per in rows}
+    rs = {per: rows[per]["rs"] / rows[per]["rs_blocks"] for per in rows}
+    assert mp[0.16] < rs[0.16]                                   # below the crossing: message passing beats RS
+    assert mp[0.20] > rs[0.20] and mp[0.22] > rs[0.22]           # beyond it: RS beats message passing alone
+    assert all(rows[per]["ml"] / rows[per]["frames"] < rs[per] for per in rows)   # MP + ML below RS at all PERs
+    assert rows[0.16]["ml"] == 0 and rows[0.18]["ml"] == 0
     tctx.close()

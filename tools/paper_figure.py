@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""BLER against packet erasure rate for the (2040,1530) code: the experiment behind the paper's figure
+"""BLER against packet erasure rate for the (2040,1530) code (--code 3: the synthesised (4080,3060) code): the experiment behind the paper's figure
 Latex/LDPC_triangular_2040_1530_Perf_vs_RS.png (Matlab/LDPCErasureCodes_MessagePassingAlgSim.m:116,134-245): binary code,
 uniform erasures `rand <= PER`, My_LDPC_Erasure_Decoder (message passing, 50 sweeps) next to My_LDPC_HybridML_Erasure_Decoder
 (10 sweeps + GF(2) elimination) and the RS(255,192)-equivalent count.  Prints one line per PER."""
@@ -39,12 +39,19 @@ def run(ctx, torch, per, nframes, seed=1, chunk=250000, code_ind=1):
 
 
 if __name__ == "__main__":
+    import argparse
     import torch
     from ldpc_erasure_codes_amd import api
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--code", type=int, default=1, help="1: (2040,1530), the authors' matrix; 3: (4080,3060), the matrix synthesised by "
+                    "tools/hgen.cpp (Latex/LDPC_triangular_4080_3060_Perf_vs_RS.png is the reference's plot for the authors' own)")
+    a = ap.parse_args()
     ctx = api.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    scale = 1 if a.code == 1 else 4
     for per, nf in ((0.14, 1000000), (0.16, 1000000), (0.18, 1000000), (0.20, 200000), (0.22, 50000)):
-        r = run(ctx, torch, per, nf)
-        print(f"PER {per:.2f}: {nf} frames  MP BLER {r['mp'] / nf:.3g} ({r['mp']})  MP+ML BLER {r['ml'] / nf:.3g} ({r['ml']}, {r['skipped']} skipped)  "
+        nf //= scale
+        r = run(ctx, torch, per, nf, code_ind=a.code)
+        print(f"code {a.code} PER {per:.2f}: {nf} frames  MP BLER {r['mp'] / nf:.3g} ({r['mp']})  MP+ML BLER {r['ml'] / nf:.3g} ({r['ml']}, {r['skipped']} skipped)  "
               f"RS BLER {r['rs'] / r['rs_blocks']:.3g}", flush=True)
     ctx.close()
