@@ -66,6 +66,13 @@ const char *ldpc_amd_last_error(const ldpc_amd_ctx *ctx);
 /* Use a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own. */
 int ldpc_amd_set_stream(ldpc_amd_ctx *ctx, void *hip_stream);
 int ldpc_amd_synchronize(ldpc_amd_ctx *ctx);
+/* Tuning / diagnostic knobs of this context (the table of DESIGN.md's appendix: "SCATTER_B", "ML_SOLVE", "HOST_PIPELINE", ... with
+ * or without the LDPC_AMD_ prefix, case-insensitive; value NULL or "" restores the shipped default).  The environment variables
+ * LDPC_AMD_<KEY> give the initial values and are read ONCE, inside ldpc_amd_init -- no call of this library looks at the process
+ * environment afterwards, so a multi-threaded host can change a knob of one context without racing another (the role of the
+ * reference's command-line options, OpenCL/host/src/main.cpp:157-170,217-246).  A knob changes how a batch is decoded, never a
+ * byte of the result.  LDPC_AMD_EINVAL for an unknown key or a value outside the knob's range. */
+int ldpc_amd_configure(ldpc_amd_ctx *ctx, const char *key, const char *value);
 
 /* ---- code ROM ----------------------------------------------------------------------------------
  * ldpc_amd_code_params: the row ldpc_params[code_ind][0..5] = {n, k, firstRow, lastRow, RS_n, RS_k}
@@ -116,7 +123,8 @@ int ldpc_amd_encode_batch(ldpc_amd_ctx *ctx, int code, int S, int64_t nframes, c
  * Matlab/My_RS_Decode_Optimize_With_GFTables.m:15):
  *   recv_idx [nblocks][k]     uint16  0-BASED strictly ascending positions (< n) of the first k received symbols
  *                                     (Matlab/ReedSolomonErasureCodes.m:80-81).  Host pointers: a violation returns
- *                                     LDPC_AMD_EINVAL; LDPC_AMD_DEVICE_PTRS: the offending block decodes to zeros.
+ *                                     LDPC_AMD_EINVAL; LDPC_AMD_DEVICE_PTRS: the offending block decodes to zeros and is
+ *                                     counted (ldpc_amd_rs_bad_blocks).
  *   recv_val [nblocks][k][S]  uint8   their values;   msg [nblocks][k][S] the recovered source block. */
 int ldpc_amd_rs_create(ldpc_amd_ctx *ctx, int n, int k);
 int ldpc_amd_rs_generator(ldpc_amd_ctx *ctx, int rs, uint8_t *g /* [k][n], host */);
@@ -124,6 +132,12 @@ int ldpc_amd_rs_encode_batch(ldpc_amd_ctx *ctx, int rs, int S, int64_t nblocks, 
                              uint8_t *codeword, unsigned flags);
 int ldpc_amd_rs_decode_batch(ldpc_amd_ctx *ctx, int rs, int S, int64_t nblocks, const uint16_t *recv_idx,
                              const uint8_t *recv_val, uint8_t *msg, unsigned flags);
+/* Number of blocks of the LAST ldpc_amd_rs_decode_batch on this context whose recv_idx was malformed (a position >= n, or
+ * not strictly ascending) and which were therefore decoded to all zeros.  Synchronises the context's stream.  The reference
+ * has no failure signalling at this point (Matlab/My_RS_Decode_Optimize_With_GFTables.m:95-97 is an empty branch; its caller
+ * guarantees the precondition, Matlab/ReedSolomonErasureCodes.m:80-81); with LDPC_AMD_DEVICE_PTRS this is how a caller tells an
+ * all-zero message from a refused block. */
+int ldpc_amd_rs_bad_blocks(ldpc_amd_ctx *ctx, long long *count);
 
 /* ---- synthetic source / channel on the device (the role of the FPGA's data_in kernel,
  * OpenCL/device/ldpc_erasure_decoder_top.cl:57-120; streams of include/ldpc_erasure_amd_synth.h).

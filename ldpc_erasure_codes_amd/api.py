@@ -29,10 +29,10 @@ ST_MP_DONE, ST_ML_SOLVED, ST_ML_RANKDEF, ST_ML_SKIPPED = 0, 1, 2, 3
 
 # every symbol include/ldpc_erasure_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "ldpc_amd_init", "ldpc_amd_cleanup", "ldpc_amd_last_error", "ldpc_amd_set_stream", "ldpc_amd_synchronize",
+    "ldpc_amd_init", "ldpc_amd_cleanup", "ldpc_amd_last_error", "ldpc_amd_set_stream", "ldpc_amd_synchronize", "ldpc_amd_configure",
     "ldpc_amd_code_params", "ldpc_amd_load_builtin_code", "ldpc_amd_register_code", "ldpc_amd_code_info",
     "ldpc_amd_code_csr", "ldpc_amd_decode_batch", "ldpc_amd_encode_batch", "ldpc_amd_rs_create",
-    "ldpc_amd_rs_generator", "ldpc_amd_rs_encode_batch", "ldpc_amd_rs_decode_batch", "ldpc_amd_synth_source",
+    "ldpc_amd_rs_generator", "ldpc_amd_rs_encode_batch", "ldpc_amd_rs_decode_batch", "ldpc_amd_rs_bad_blocks", "ldpc_amd_synth_source",
     "ldpc_amd_synth_erasures_uniform", "ldpc_amd_synth_erasures_bursty", "ldpc_amd_data_in", "ldpc_amd_ldpc_erasure_decoder", "ldpc_amd_data_out",
     "ldpc_amd_ldpc_erasure_decoder_perf_tests", "ldpc_amd_fpga_frame_stats", "ldpc_amd_profile_kernel_name", "ldpc_amd_last_plan",
     "ldpc_amd_fec_header_pack", "ldpc_amd_fec_header_unpack", "ldpc_amd_fec_packetize", "ldpc_amd_fec_rx_create",
@@ -76,6 +76,8 @@ def load_library():
     L.ldpc_amd_last_error.restype = C.c_char_p
     L.ldpc_amd_set_stream.argtypes = [vp, vp]
     L.ldpc_amd_synchronize.argtypes = [vp]
+    if hasattr(L, "ldpc_amd_configure"):   # (tools/ab_lib.py and tools/time_latency.py also load older builds of the library)
+        L.ldpc_amd_configure.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.ldpc_amd_code_params.argtypes = [i32, C.POINTER(i32)]
     L.ldpc_amd_load_builtin_code.argtypes = [vp, i32, u64]
     L.ldpc_amd_register_code.argtypes = [vp, i32, i32, vp, vp, vp]
@@ -87,6 +89,8 @@ def load_library():
     L.ldpc_amd_rs_generator.argtypes = [vp, i32, vp]
     L.ldpc_amd_rs_encode_batch.argtypes = [vp, i32, i32, i64, vp, vp, C.c_uint]
     L.ldpc_amd_rs_decode_batch.argtypes = [vp, i32, i32, i64, vp, vp, vp, C.c_uint]
+    if hasattr(L, "ldpc_amd_rs_bad_blocks"):
+        L.ldpc_amd_rs_bad_blocks.argtypes = [vp, C.POINTER(C.c_longlong)]
     L.ldpc_amd_synth_source.argtypes = [vp, u64, i64, i64, i32, i32, vp]
     L.ldpc_amd_synth_erasures_uniform.argtypes = [vp, u64, i64, i64, i32, C.c_double, vp]
     L.ldpc_amd_synth_erasures_bursty.argtypes = [vp, u64, i64, i64, i32, C.c_double, C.c_double, C.c_double, vp]
@@ -191,6 +195,17 @@ class Context:
 
     def synchronize(self):
         self._check(self._L.ldpc_amd_synchronize(self._h), "synchronize")
+
+    def configure(self, key, value=None):
+        """Sets a tuning / diagnostic knob of this context ("SCATTER_B", "LDPC_AMD_ML_SOLVE", ...); value None restores the
+        default.  The LDPC_AMD_* environment variables are only the initial values, read once when the context is created."""
+        v = None if value is None else str(value).encode()
+        self._check(self._L.ldpc_amd_configure(self._h, key.encode(), v), "configure")
+
+    def configure_many(self, knobs):
+        """{key: value or None} -> configure() for each."""
+        for k, v in knobs.items():
+            self.configure(k, v)
 
     def set_profiling(self, enable):
         self._check(self._L.ldpc_amd_set_profiling(self._h, int(bool(enable))), "set_profiling")
@@ -336,6 +351,12 @@ class Context:
         self._check(self._L.ldpc_amd_rs_decode_batch(self._h, rs, S, B, _ptr(recv_idx), _ptr(recv_val), _ptr(msg),
                                                      DEVICE_PTRS if dev else 0), "rs_decode_batch")
         return msg
+
+    def rs_bad_blocks(self):
+        """Blocks of the last rs_decode whose positions were malformed (decoded to zeros).  Synchronises."""
+        c = C.c_longlong(0)
+        self._check(self._L.ldpc_amd_rs_bad_blocks(self._h, C.byref(c)), "rs_bad_blocks")
+        return c.value
 
     # -- synthetic inputs on the device (torch tensors)
     def synth_source(self, seed, frame0, nframes, k, S, out):

@@ -1,7 +1,9 @@
 // api.cpp -- the C ABI of include/ldpc_erasure_amd.h (host side only; kernels live in kernels.hip).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <strings.h>
 
 #include <algorithm>
 #include <condition_variable>
@@ -51,6 +53,77 @@ void build_mul3_tables(uint32_t *tab)
         for (int w = 0; w < 8; w++)
             tab[c * 8 + w] = (uint32_t)b[4 * w] | ((uint32_t)b[4 * w + 1] << 8) | ((uint32_t)b[4 * w + 2] << 16) |
                              ((uint32_t)b[4 * w + 3] << 24);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// knobs: one table, read from the environment once per context (ldpc_amd_init) or set by ldpc_amd_configure
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct KnobDesc {
+    const char *name;                                    // without the LDPC_AMD_ prefix
+    bool (*set)(Knobs &, const char *value);             // value != nullptr
+    void (*reset)(Knobs &);                              // back to the shipped default
+};
+static bool parse_ll(const char *v, long long *out)
+{
+    char *end = nullptr;
+    const long long x = strtoll(v, &end, 10);
+    if (end == v || *end != '\0') return false;
+    *out = x;
+    return true;
+}
+#define LDPC_KNOB_INT(NAME, FIELD, COND)                                                                                          \
+    {NAME, [](Knobs &k, const char *v) { long long x; if (!parse_ll(v, &x) || !(COND)) return false; k.FIELD = (decltype(k.FIELD))x; return true; }, \
+     [](Knobs &k) { k.FIELD = Knobs{}.FIELD; }}
+static const KnobDesc kKnobs[] = {
+    {"APPLY", [](Knobs &k, const char *v) { if (!strcmp(v, "gather")) k.apply_gather = 1; else if (!strcmp(v, "scatter")) k.apply_gather = 0; else return false; return true; },
+     [](Knobs &k) { k.apply_gather = 0; }},
+    LDPC_KNOB_INT("SCATTER_B", scatter_b, x == 256 || x == 128 || x == 64),
+    LDPC_KNOB_INT("SCATTER_TIERS", scatter_tiers, x == 1 || x == 2),
+    LDPC_KNOB_INT("SCATTER_NT", scatter_nt, x == 0 || x == 1),
+    LDPC_KNOB_INT("SCATTER_XCD", scatter_xcd, x == 0 || x == 1),
+    LDPC_KNOB_INT("SCATTER_DYN", scatter_dyn, x >= 0 && x <= 4),
+    LDPC_KNOB_INT("SCATTER_R", scatter_r, x == 1 || x == 2 || x == 4),
+    LDPC_KNOB_INT("SCATTER_R2", scatter_r2, x >= 2 && x <= 4),
+    LDPC_KNOB_INT("PEEL_WPB", peel_wpb, x >= 0 && x <= 16),
+    LDPC_KNOB_INT("PEEL_GT", peel_gt, x >= -1 && x <= 1),
+    LDPC_KNOB_INT("ML_SOLVE", ml_solve, x >= 0 && x <= 2),
+    LDPC_KNOB_INT("ML_DBG", ml_dbg, x >= 0),
+    LDPC_KNOB_INT("ML_SOLVE_B", ml_solve_b, x == 16 || x == 32 || x == 64 || x == 128),
+    LDPC_KNOB_INT("ML_ARENA_WORDS", ml_arena_words, x == 0 || x >= 1024),
+    LDPC_KNOB_INT("ML_THREADS", ml_threads, x == 0 || (x >= 256 && x <= 1024 && (x % 64) == 0)),
+    LDPC_KNOB_INT("ML_PACK", ml_pack, x >= 1 && x <= 4),
+    LDPC_KNOB_INT("ML_RHS", ml_rhs, x == 0 || x == 1),
+    LDPC_KNOB_INT("ENC_B", enc_b, x == 128 || x == 256),
+    LDPC_KNOB_INT("ENC_LIST", enc_list, x == 0 || x == 1),
+    {"RS", [](Knobs &k, const char *v) { if (!strcmp(v, "generic")) k.rs_generic = 1; else if (!strcmp(v, "fast")) k.rs_generic = 0; else return false; return true; },
+     [](Knobs &k) { k.rs_generic = 0; }},
+    LDPC_KNOB_INT("HOST_PIPELINE", host_pipeline, x == 0 || x == 1),
+    LDPC_KNOB_INT("FPGA_CHUNK", fpga_chunk, x >= 1),
+};
+#undef LDPC_KNOB_INT
+}  // namespace
+
+int knob_set(Knobs &k, const char *key, const char *value)
+{
+    if (!key) return -1;
+    if (!strncasecmp(key, "LDPC_AMD_", 9)) key += 9;
+    for (const KnobDesc &d : kKnobs) {
+        if (strcasecmp(key, d.name)) continue;
+        if (!value || !*value) { d.reset(k); return 0; }
+        return d.set(k, value) ? 0 : -1;
+    }
+    return -1;
+}
+
+void knobs_from_env(Knobs &k)
+{
+    char name[64];
+    for (const KnobDesc &d : kKnobs) {
+        snprintf(name, sizeof(name), "LDPC_AMD_%s", d.name);
+        const char *v = getenv(name);   // the ONLY getenv of the library: once per context, inside ldpc_amd_init
+        if (v && *v) (void)d.set(k, v); // a malformed value leaves the default, like the per-call parsing it replaces
     }
 }
 
@@ -329,6 +402,147 @@ struct Staged {
     int32_t *sweeps = nullptr, *residual = nullptr, *status = nullptr;
 };
 
+// Host buffers, large batch: the reference's three FPGA kernels (data_in / decoder / data_out, coupled by channels,
+// OpenCL/host/src/main.cpp:513-517,617-625) run concurrently; the equivalent here is a chunked pipeline in which the
+// upload of chunk c+1, the kernels of chunk c and the download of chunk c-1 overlap.  Caller memory is pageable, so a
+// copy call occupies its calling thread: uploads and kernel launches are issued from this thread, downloads from a
+// helper thread, each on its own stream; device staging is double-buffered.  One helper for every host-pointer entry
+// point (decode, encode, RS encode, RS decode): up to two input arrays and up to four output arrays, each `item_bytes`
+// per item (frame or block); launch(count, in0, in1, out0, out1, out2, out3) enqueues the kernels of one chunk on the
+// context's stream.
+struct PipeIn {
+    const void *host = nullptr;
+    size_t item_bytes = 0;
+};
+struct PipeOut {
+    void *host = nullptr;      // nullptr: the array is produced on the device but not downloaded
+    size_t item_bytes = 0;     // 0: unused slot
+};
+static const size_t kPipeChunkBytes = (size_t)96 << 20;    // device staging per chunk and array
+static const size_t kPipeThreshold = (size_t)192 << 20;    // batches below this go in one shot
+
+template <class Launch>
+static int host_pipeline(ldpc_amd_ctx *ctx, int64_t nitems, const PipeIn (&ins)[2], const PipeOut (&outs)[4], Launch launch)
+{
+    size_t big = 1;
+    for (const PipeIn &i : ins) big = std::max(big, i.item_bytes);
+    for (const PipeOut &o : outs) big = std::max(big, o.item_bytes);
+    const int64_t C = std::max<int64_t>(1, std::min<int64_t>(nitems, (int64_t)(kPipeChunkBytes / big)));
+    const int64_t nc = (nitems + C - 1) / C;
+    // small output arrays (the three status words of the decoder) share one staging block
+    size_t small_stride[4] = {0, 0, 0, 0}, small_total = 0;
+    for (int i = 1; i < 4; i++) { small_stride[i] = small_total; small_total += ((outs[i].item_bytes * (size_t)C + 255) & ~(size_t)255); }
+    int rc;
+    if ((rc = scratch_reserve(ctx, ctx->stage_in, 2 * std::max<size_t>(ins[0].item_bytes, 1) * C)) ||
+        (rc = scratch_reserve(ctx, ctx->stage_er, 2 * std::max<size_t>(ins[1].item_bytes, 1) * C)) ||
+        (rc = scratch_reserve(ctx, ctx->stage_out, 2 * std::max<size_t>(outs[0].item_bytes, 1) * C)) ||
+        (rc = scratch_reserve(ctx, ctx->stage_i32, 2 * std::max<size_t>(small_total, 256))))
+        return rc;
+    if (!ctx->aux_in) LDPC_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_in, hipStreamNonBlocking));
+    if (!ctx->aux_out) LDPC_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_out, hipStreamNonBlocking));
+    // the five events live in the context (created once, destroyed by ldpc_amd_cleanup): no error path leaks them
+    for (int i = 0; i < 5; i++)
+        if (!ctx->pipe_events[i]) LDPC_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pipe_events[i], hipEventDisableTiming));
+    hipEvent_t e_in[2] = {ctx->pipe_events[0], ctx->pipe_events[1]}, e_k[2] = {ctx->pipe_events[2], ctx->pipe_events[3]};
+    hipEvent_t e_free = ctx->pipe_events[4];
+    // the staging buffers may still be in use by earlier work on the context's stream
+    LDPC_HIP_TRY(ctx, hipEventRecord(e_free, ctx->stream));
+    LDPC_HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_in, e_free, 0));
+
+    std::mutex mu;
+    std::condition_variable cv;
+    int64_t launched = 0, downloaded = 0;   // chunks whose kernels have been enqueued / whose results are on the host
+    bool failed = false;
+    std::string helper_err;
+    const int device = ctx->device;
+    hipStream_t s_out = ctx->aux_out;
+    uint8_t *dev_out0 = (uint8_t *)ctx->stage_out.p;
+    uint8_t *dev_small = (uint8_t *)ctx->stage_i32.p;
+    const size_t small_buf = std::max<size_t>(small_total, 256);
+    auto dev_out = [&](int i, int b) -> uint8_t * {
+        return i == 0 ? dev_out0 + (size_t)b * outs[0].item_bytes * C : dev_small + (size_t)b * small_buf + small_stride[i];
+    };
+
+    std::thread helper;
+    auto helper_body = [&]() {
+        (void)hipSetDevice(device);
+        for (int64_t c = 0; c < nc; c++) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return launched > c || failed; });
+                if (failed) return;
+            }
+            const int b = (int)(c & 1);
+            const int64_t f0 = c * C, cnt = std::min(C, nitems - f0);
+            hipError_t e = hipStreamWaitEvent(s_out, e_k[b], 0);
+            for (int i = 0; i < 4 && e == hipSuccess; i++)
+                if (outs[i].host && outs[i].item_bytes)
+                    e = hipMemcpyAsync((uint8_t *)outs[i].host + (size_t)f0 * outs[i].item_bytes, dev_out(i, b), outs[i].item_bytes * cnt, hipMemcpyDeviceToHost, s_out);
+            if (e == hipSuccess) e = hipStreamSynchronize(s_out);
+            std::lock_guard<std::mutex> lk(mu);
+            if (e != hipSuccess) { failed = true; helper_err = hipGetErrorString(e); cv.notify_all(); return; }
+            downloaded = c + 1;
+            cv.notify_all();
+        }
+    };
+    try {
+        helper = std::thread(helper_body);
+    } catch (...) {   // std::system_error must not cross the C ABI
+        return set_error(ctx, LDPC_AMD_ENOMEM, "host pipeline: could not start the download thread");
+    }
+
+    int result = LDPC_AMD_OK;
+    for (int64_t c = 0; c < nc && result == LDPC_AMD_OK; c++) {
+        const int b = (int)(c & 1);
+        const int64_t f0 = c * C, cnt = std::min(C, nitems - f0);
+        uint8_t *din0 = (uint8_t *)ctx->stage_in.p + (size_t)b * ins[0].item_bytes * C, *din1 = (uint8_t *)ctx->stage_er.p + (size_t)b * ins[1].item_bytes * C;
+        hipError_t e = hipSuccess;
+        if (c >= 2) e = hipStreamWaitEvent(ctx->aux_in, e_k[b], 0);          // in[b] was read by the kernels of chunk c-2
+        if (e == hipSuccess && ins[0].item_bytes) e = hipMemcpyAsync(din0, (const uint8_t *)ins[0].host + (size_t)f0 * ins[0].item_bytes, ins[0].item_bytes * cnt, hipMemcpyHostToDevice, ctx->aux_in);
+        if (e == hipSuccess && ins[1].item_bytes) e = hipMemcpyAsync(din1, (const uint8_t *)ins[1].host + (size_t)f0 * ins[1].item_bytes, ins[1].item_bytes * cnt, hipMemcpyHostToDevice, ctx->aux_in);
+        if (e == hipSuccess) e = hipEventRecord(e_in[b], ctx->aux_in);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, e_in[b], 0);
+        if (e != hipSuccess) { result = set_error(ctx, LDPC_AMD_EHIP, "host pipeline: %s", hipGetErrorString(e)); break; }
+        {   // out[b] and e_k[b] belong to chunk c-2 until its results are on the host
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return downloaded >= c - 1 || failed; });
+            if (failed) break;
+        }
+        if ((rc = launch(cnt, din0, din1, dev_out(0, b), dev_out(1, b), dev_out(2, b), dev_out(3, b)))) { result = rc; break; }
+        e = hipEventRecord(e_k[b], ctx->stream);
+        if (e != hipSuccess) { result = set_error(ctx, LDPC_AMD_EHIP, "host pipeline: %s", hipGetErrorString(e)); break; }
+        std::lock_guard<std::mutex> lk(mu);
+        launched = c + 1;
+        cv.notify_all();
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (result != LDPC_AMD_OK) failed = true;
+        cv.notify_all();
+    }
+    helper.join();
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->aux_in);
+    (void)hipStreamSynchronize(ctx->aux_out);
+    if (result == LDPC_AMD_OK && failed) result = set_error(ctx, LDPC_AMD_EHIP, "host pipeline (download): %s", helper_err.c_str());
+    return result;
+}
+
+// Small host-pointer calls (a single Matlab-style frame is the extreme): the call is bound by the NUMBER of runtime calls, not
+// by bytes -- two copies in, four out, each a separate pageable transfer.  Inputs are packed into one pinned block (one
+// upload), outputs come back as one download and are unpacked on the host.
+static const size_t kSmallCall = (size_t)1 << 20;
+static int pinned_reserve(ldpc_amd_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->pin_cap) return LDPC_AMD_OK;
+    if (ctx->pin) { (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(ctx->pin); ctx->pin = nullptr; ctx->pin_cap = 0; }
+    const size_t want = std::max<size_t>(bytes, 2 * kSmallCall);
+    hipError_t e = hipHostMalloc(&ctx->pin, want, hipHostMallocDefault);
+    if (e != hipSuccess) { ctx->pin = nullptr; return set_error(ctx, LDPC_AMD_ENOMEM, "hipHostMalloc(%zu): %s", want, hipGetErrorString(e)); }
+    ctx->pin_cap = want;
+    return LDPC_AMD_OK;
+}
+
 }  // namespace ldpc_amd
 
 using namespace ldpc_amd;
@@ -362,6 +576,7 @@ int ldpc_amd_init(int device_ordinal, ldpc_amd_ctx **out)
     if (!ctx) return set_error(nullptr, LDPC_AMD_ENOMEM, "out of host memory");
     ctx->device = device_ordinal;
     ctx->sm_count = prop.multiProcessorCount;
+    knobs_from_env(ctx->knobs);   // the environment is looked at here and nowhere else
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
         delete ctx;
         return set_error(nullptr, LDPC_AMD_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
@@ -388,7 +603,7 @@ void ldpc_amd_cleanup(ldpc_amd_ctx *ctx)
         delete r;
     }
     Scratch *all[] = {&ctx->sched, &ctx->mlws, &ctx->mlstate, &ctx->mlops, &ctx->mlrec, &ctx->mllist, &ctx->biglist, &ctx->stage_in, &ctx->stage_er,
-                      &ctx->stage_out, &ctx->stage_i32, &ctx->rsws, &ctx->fpga_erased, &ctx->fpga_stats};
+                      &ctx->stage_out, &ctx->stage_i32, &ctx->rsws, &ctx->rsbad, &ctx->fpga_erased, &ctx->fpga_stats};
     for (Scratch *s : all) scratch_free(*s);
     for (auto &v : ctx->prof_events)
         for (auto &pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -398,6 +613,7 @@ void ldpc_amd_cleanup(ldpc_amd_ctx *ctx)
     if (ctx->aux_in) (void)hipStreamDestroy(ctx->aux_in);
     if (ctx->aux_out) (void)hipStreamDestroy(ctx->aux_out);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     delete ctx;
 }
 
@@ -413,6 +629,14 @@ int ldpc_amd_set_stream(ldpc_amd_ctx *ctx, void *hip_stream)
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_configure(ldpc_amd_ctx *ctx, const char *key, const char *value)
+{
+    if (!ctx) return LDPC_AMD_EINVAL;
+    if (knob_set(ctx->knobs, key, value))
+        return set_error(ctx, LDPC_AMD_EINVAL, "ldpc_amd_configure: unknown key or bad value: %s = %s", key ? key : "(null)", value ? value : "(default)");
     return LDPC_AMD_OK;
 }
 
@@ -470,114 +694,6 @@ int ldpc_amd_code_csr(ldpc_amd_ctx *ctx, int code, uint32_t *row_ptr, uint16_t *
     return LDPC_AMD_OK;
 }
 
-// Host buffers, large batch: the reference's three FPGA kernels (data_in / decoder / data_out, coupled by channels,
-// OpenCL/host/src/main.cpp:513-517,617-625) run concurrently; the equivalent here is a chunked pipeline in which the
-// upload of chunk c+1, the decode of chunk c and the download of chunk c-1 overlap.  Caller memory is pageable, so a
-// copy call occupies its calling thread: uploads and kernel launches are issued from this thread, downloads from a
-// helper thread, each on its own stream; device staging is double-buffered.
-static int decode_host_pipelined(ldpc_amd_ctx *ctx, HostCode *hc, DecodeArgs d, const uint8_t *sym, const uint8_t *erased,
-                                 uint8_t *out, int32_t *sweeps, int32_t *residual, int32_t *status)
-{
-    const int64_t nframes = d.nframes;
-    const size_t fbytes = (size_t)hc->n * d.S, ebytes = (size_t)hc->n;
-    const int64_t C = std::max<int64_t>(1, std::min<int64_t>(nframes, (int64_t)(((size_t)96 << 20) / fbytes)));
-    const int64_t nc = (nframes + C - 1) / C;
-    int rc;
-    if ((rc = scratch_reserve(ctx, ctx->stage_in, 2 * fbytes * C)) || (rc = scratch_reserve(ctx, ctx->stage_er, 2 * ebytes * C)) ||
-        (rc = scratch_reserve(ctx, ctx->stage_out, 2 * fbytes * C)) || (rc = scratch_reserve(ctx, ctx->stage_i32, 2 * 3 * sizeof(int32_t) * (size_t)C)))
-        return rc;
-    if (!ctx->aux_in) LDPC_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_in, hipStreamNonBlocking));
-    if (!ctx->aux_out) LDPC_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_out, hipStreamNonBlocking));
-    // the five events live in the context (created once, destroyed by ldpc_amd_cleanup): no error path leaks them
-    for (int i = 0; i < 5; i++)
-        if (!ctx->pipe_events[i]) LDPC_HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->pipe_events[i], hipEventDisableTiming));
-    hipEvent_t e_in[2] = {ctx->pipe_events[0], ctx->pipe_events[1]}, e_k[2] = {ctx->pipe_events[2], ctx->pipe_events[3]};
-    hipEvent_t e_free = ctx->pipe_events[4];
-    // the staging buffers may still be in use by earlier work on the context's stream
-    LDPC_HIP_TRY(ctx, hipEventRecord(e_free, ctx->stream));
-    LDPC_HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_in, e_free, 0));
-
-    std::mutex mu;
-    std::condition_variable cv;
-    int64_t launched = 0, downloaded = 0;   // chunks whose decode has been enqueued / whose results are on the host
-    bool failed = false;
-    std::string helper_err;
-    const int device = ctx->device;
-    hipStream_t s_out = ctx->aux_out;
-    uint8_t *dev_out = (uint8_t *)ctx->stage_out.p;
-    int32_t *dev_i32 = (int32_t *)ctx->stage_i32.p;
-
-    std::thread helper;
-    auto helper_body = [&]() {
-        (void)hipSetDevice(device);
-        for (int64_t c = 0; c < nc; c++) {
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return launched > c || failed; });
-                if (failed) return;
-            }
-            const int b = (int)(c & 1);
-            const int64_t f0 = c * C, cnt = std::min(C, nframes - f0);
-            const int32_t *i32 = dev_i32 + (size_t)b * 3 * C;
-            hipError_t e = hipStreamWaitEvent(s_out, e_k[b], 0);
-            if (e == hipSuccess) e = hipMemcpyAsync(out + (size_t)f0 * fbytes, dev_out + (size_t)b * fbytes * C, fbytes * cnt, hipMemcpyDeviceToHost, s_out);
-            if (e == hipSuccess && sweeps) e = hipMemcpyAsync(sweeps + f0, i32, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, s_out);
-            if (e == hipSuccess && residual) e = hipMemcpyAsync(residual + f0, i32 + C, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, s_out);
-            if (e == hipSuccess && status) e = hipMemcpyAsync(status + f0, i32 + 2 * C, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost, s_out);
-            if (e == hipSuccess) e = hipStreamSynchronize(s_out);
-            std::lock_guard<std::mutex> lk(mu);
-            if (e != hipSuccess) { failed = true; helper_err = hipGetErrorString(e); cv.notify_all(); return; }
-            downloaded = c + 1;
-            cv.notify_all();
-        }
-    };
-    try {
-        helper = std::thread(helper_body);
-    } catch (...) {   // std::system_error must not cross the C ABI
-        return set_error(ctx, LDPC_AMD_ENOMEM, "host pipeline: could not start the download thread");
-    }
-
-    int result = LDPC_AMD_OK;
-    for (int64_t c = 0; c < nc && result == LDPC_AMD_OK; c++) {
-        const int b = (int)(c & 1);
-        const int64_t f0 = c * C, cnt = std::min(C, nframes - f0);
-        uint8_t *din = (uint8_t *)ctx->stage_in.p + (size_t)b * fbytes * C, *der = (uint8_t *)ctx->stage_er.p + (size_t)b * ebytes * C;
-        hipError_t e = hipSuccess;
-        if (c >= 2) e = hipStreamWaitEvent(ctx->aux_in, e_k[b], 0);          // in[b] was read by the decode of chunk c-2
-        if (e == hipSuccess) e = hipMemcpyAsync(din, sym + (size_t)f0 * fbytes, fbytes * cnt, hipMemcpyHostToDevice, ctx->aux_in);
-        if (e == hipSuccess) e = hipMemcpyAsync(der, erased + (size_t)f0 * ebytes, ebytes * cnt, hipMemcpyHostToDevice, ctx->aux_in);
-        if (e == hipSuccess) e = hipEventRecord(e_in[b], ctx->aux_in);
-        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, e_in[b], 0);
-        if (e != hipSuccess) { result = set_error(ctx, LDPC_AMD_EHIP, "host pipeline: %s", hipGetErrorString(e)); break; }
-        {   // out[b], i32[b] and e_k[b] belong to chunk c-2 until its results are on the host
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return downloaded >= c - 1 || failed; });
-            if (failed) break;
-        }
-        DecodeArgs dc = d;
-        dc.nframes = cnt; dc.sym = din; dc.erased = der; dc.out = dev_out + (size_t)b * fbytes * C;
-        int32_t *i32 = dev_i32 + (size_t)b * 3 * C;
-        dc.sweeps = i32; dc.residual = i32 + C; dc.status = i32 + 2 * C;
-        if ((rc = launch_decode(ctx, dc))) { result = rc; break; }
-        e = hipEventRecord(e_k[b], ctx->stream);
-        if (e != hipSuccess) { result = set_error(ctx, LDPC_AMD_EHIP, "host pipeline: %s", hipGetErrorString(e)); break; }
-        std::lock_guard<std::mutex> lk(mu);
-        launched = c + 1;
-        cv.notify_all();
-    }
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        if (result != LDPC_AMD_OK) failed = true;
-        cv.notify_all();
-    }
-    helper.join();
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamSynchronize(ctx->aux_in);
-    (void)hipStreamSynchronize(ctx->aux_out);
-    if (result == LDPC_AMD_OK && failed) result = set_error(ctx, LDPC_AMD_EHIP, "host pipeline (download): %s", helper_err.c_str());
-    return result;
-}
-
 int ldpc_amd_decode_batch(ldpc_amd_ctx *ctx, int code, int S, int64_t nframes, const uint8_t *sym,
                           const uint8_t *erased, int max_sweeps, int do_ml, uint8_t *out, int32_t *sweeps,
                           int32_t *residual, int32_t *status, unsigned flags)
@@ -601,10 +717,39 @@ int ldpc_amd_decode_batch(ldpc_amd_ctx *ctx, int code, int S, int64_t nframes, c
     }
     if (flags & LDPC_AMD_INPLACE) return set_error(ctx, LDPC_AMD_EINVAL, "LDPC_AMD_INPLACE needs LDPC_AMD_DEVICE_PTRS");
     int rc;
-    {
-        const char *env_p = getenv("LDPC_AMD_HOST_PIPELINE");
-        if (fbytes * (size_t)nframes >= ((size_t)192 << 20) && !(env_p && atoi(env_p) == 0))
-            return decode_host_pipelined(ctx, hc, d, sym, erased, out, sweeps, residual, status);
+    const size_t ebytes = (size_t)hc->n;
+    if (fbytes * (size_t)nframes >= kPipeThreshold && ctx->knobs.host_pipeline) {
+        const PipeIn ins[2] = {{sym, fbytes}, {erased, ebytes}};
+        const PipeOut outs[4] = {{out, fbytes}, {sweeps, sizeof(int32_t)}, {residual, sizeof(int32_t)}, {status, sizeof(int32_t)}};
+        return host_pipeline(ctx, nframes, ins, outs, [&](int64_t cnt, uint8_t *i0, uint8_t *i1, uint8_t *o0, uint8_t *o1, uint8_t *o2, uint8_t *o3) {
+            DecodeArgs dc = d;
+            dc.nframes = cnt; dc.sym = i0; dc.erased = i1; dc.out = o0;
+            dc.sweeps = (int32_t *)o1; dc.residual = (int32_t *)o2; dc.status = (int32_t *)o3;
+            return launch_decode(ctx, dc);
+        });
+    }
+    const size_t in_b = (fbytes + ebytes) * nframes, out_b = (fbytes + 3 * sizeof(int32_t)) * nframes;
+    if (in_b + out_b + 64 <= kSmallCall) {
+        // one upload, one download (pinned bounce block): sym | erased -> device ; out | sweeps | residual | status <- device
+        const size_t o_er = (fbytes * nframes + 15) & ~(size_t)15, o_out = (o_er + ebytes * nframes + 15) & ~(size_t)15;
+        const size_t o_i32 = (o_out + fbytes * nframes + 15) & ~(size_t)15, total = o_i32 + 3 * sizeof(int32_t) * nframes;
+        if ((rc = pinned_reserve(ctx, total)) || (rc = scratch_reserve(ctx, ctx->stage_in, std::max(total, 2 * kSmallCall)))) return rc;
+        uint8_t *hp = (uint8_t *)ctx->pin, *dp = (uint8_t *)ctx->stage_in.p;
+        memcpy(hp, sym, fbytes * nframes);
+        memcpy(hp + o_er, erased, ebytes * nframes);
+        LDPC_HIP_TRY(ctx, hipMemcpyAsync(dp, hp, o_out, hipMemcpyHostToDevice, ctx->stream));
+        int32_t *i32 = (int32_t *)(dp + o_i32);
+        d.sym = dp; d.erased = dp + o_er; d.out = dp + o_out;
+        d.sweeps = i32; d.residual = i32 + nframes; d.status = i32 + 2 * nframes;
+        if ((rc = launch_decode(ctx, d))) return rc;
+        LDPC_HIP_TRY(ctx, hipMemcpyAsync(hp + o_out, dp + o_out, total - o_out, hipMemcpyDeviceToHost, ctx->stream));
+        LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(out, hp + o_out, fbytes * nframes);
+        const int32_t *h32 = (const int32_t *)(hp + o_i32);
+        if (sweeps) memcpy(sweeps, h32, sizeof(int32_t) * nframes);
+        if (residual) memcpy(residual, h32 + nframes, sizeof(int32_t) * nframes);
+        if (status) memcpy(status, h32 + 2 * nframes, sizeof(int32_t) * nframes);
+        return LDPC_AMD_OK;
     }
     if ((rc = scratch_reserve(ctx, ctx->stage_in, fbytes * nframes)) || (rc = scratch_reserve(ctx, ctx->stage_er, (size_t)hc->n * nframes)) ||
         (rc = scratch_reserve(ctx, ctx->stage_out, fbytes * nframes)) || (rc = scratch_reserve(ctx, ctx->stage_i32, 3 * sizeof(int32_t) * (size_t)nframes)))
@@ -636,6 +781,13 @@ int ldpc_amd_encode_batch(ldpc_amd_ctx *ctx, int code, int S, int64_t nframes, c
     if (flags & LDPC_AMD_DEVICE_PTRS) return launch_encode(ctx, hc->dev, S, nframes, source, codeword);
     const size_t ib = (size_t)hc->k * S * nframes, ob = (size_t)hc->n * S * nframes;
     int rc;
+    if (ob >= kPipeThreshold && ctx->knobs.host_pipeline) {   // large batch: upload / encode / download overlap, chunk by chunk
+        const PipeIn ins[2] = {{source, (size_t)hc->k * S}, {nullptr, 0}};
+        const PipeOut outs[4] = {{codeword, (size_t)hc->n * S}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}};
+        return host_pipeline(ctx, nframes, ins, outs, [&](int64_t cnt, uint8_t *i0, uint8_t *, uint8_t *o0, uint8_t *, uint8_t *, uint8_t *) {
+            return launch_encode(ctx, hc->dev, S, cnt, i0, o0);
+        });
+    }
     if ((rc = scratch_reserve(ctx, ctx->stage_in, ib)) || (rc = scratch_reserve(ctx, ctx->stage_out, ob))) return rc;
     LDPC_HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_in.p, source, ib, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = launch_encode(ctx, hc->dev, S, nframes, (const uint8_t *)ctx->stage_in.p, (uint8_t *)ctx->stage_out.p))) return rc;
@@ -739,6 +891,13 @@ int ldpc_amd_rs_encode_batch(ldpc_amd_ctx *ctx, int rs, int S, int64_t nblocks, 
     if (flags & LDPC_AMD_DEVICE_PTRS) return launch_rs_encode(ctx, *r, S, nblocks, source, codeword);
     const size_t ib = (size_t)r->k * S * nblocks, ob = (size_t)r->n * S * nblocks;
     int rc;
+    if (ob >= kPipeThreshold && ctx->knobs.host_pipeline) {
+        const PipeIn ins[2] = {{source, (size_t)r->k * S}, {nullptr, 0}};
+        const PipeOut outs[4] = {{codeword, (size_t)r->n * S}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}};
+        return host_pipeline(ctx, nblocks, ins, outs, [&](int64_t cnt, uint8_t *i0, uint8_t *, uint8_t *o0, uint8_t *, uint8_t *, uint8_t *) {
+            return launch_rs_encode(ctx, *r, S, cnt, i0, o0);
+        });
+    }
     if ((rc = scratch_reserve(ctx, ctx->stage_in, ib)) || (rc = scratch_reserve(ctx, ctx->stage_out, ob))) return rc;
     LDPC_HIP_TRY(ctx, hipMemcpyAsync(ctx->stage_in.p, source, ib, hipMemcpyHostToDevice, ctx->stream));
     if ((rc = launch_rs_encode(ctx, *r, S, nblocks, (const uint8_t *)ctx->stage_in.p, (uint8_t *)ctx->stage_out.p))) return rc;
@@ -767,6 +926,13 @@ int ldpc_amd_rs_decode_batch(ldpc_amd_ctx *ctx, int rs, int S, int64_t nblocks, 
     }
     const size_t vb = (size_t)r->k * S * nblocks, xb = (size_t)r->k * 2 * nblocks;
     int rc;
+    if (vb >= kPipeThreshold && ctx->knobs.host_pipeline) {
+        const PipeIn ins[2] = {{recv_val, (size_t)r->k * S}, {recv_idx, (size_t)r->k * 2}};
+        const PipeOut outs[4] = {{msg, (size_t)r->k * S}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}};
+        return host_pipeline(ctx, nblocks, ins, outs, [&](int64_t cnt, uint8_t *i0, uint8_t *i1, uint8_t *o0, uint8_t *, uint8_t *, uint8_t *) {
+            return launch_rs_decode(ctx, *r, S, cnt, (const uint16_t *)i1, i0, o0);
+        });
+    }
     if ((rc = scratch_reserve(ctx, ctx->stage_in, vb)) || (rc = scratch_reserve(ctx, ctx->stage_er, xb)) ||
         (rc = scratch_reserve(ctx, ctx->stage_out, vb)))
         return rc;
@@ -777,6 +943,19 @@ int ldpc_amd_rs_decode_batch(ldpc_amd_ctx *ctx, int rs, int S, int64_t nblocks, 
         return rc;
     LDPC_HIP_TRY(ctx, hipMemcpyAsync(msg, ctx->stage_out.p, vb, hipMemcpyDeviceToHost, ctx->stream));
     LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_rs_bad_blocks(ldpc_amd_ctx *ctx, long long *count)
+{
+    if (!ctx || !count) return ctx ? set_error(ctx, LDPC_AMD_EINVAL, "null count pointer") : LDPC_AMD_EINVAL;
+    *count = 0;
+    if (!ctx->rsbad.p) return LDPC_AMD_OK;   // no RS decode ran on this context yet
+    LDPC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int v = 0;
+    LDPC_HIP_TRY(ctx, hipMemcpyAsync(&v, ctx->rsbad.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *count = v;
     return LDPC_AMD_OK;
 }
 
@@ -819,12 +998,7 @@ static int fpga_code(ldpc_amd_ctx *ctx, int code_ind)
 }
 
 // Frames per chunk of the streamed run (LDPC_AMD_FPGA_CHUNK overrides it: tests use small chunks to cross chunk borders).
-static long fpga_chunk_frames()
-{
-    const char *e = getenv("LDPC_AMD_FPGA_CHUNK");
-    const long v = e ? atol(e) : 0;
-    return v > 0 ? v : 65536;
-}
+static long fpga_chunk_frames(const ldpc_amd_ctx *ctx) { return ctx->knobs.fpga_chunk > 0 ? ctx->knobs.fpga_chunk : 65536; }
 // Runs up to this many frames keep their per-frame results for ldpc_amd_fpga_frame_stats (8 bytes per frame).
 static const long kFpgaKeepFrames = 1l << 22;
 
@@ -860,7 +1034,7 @@ static int fpga_run(ldpc_amd_ctx *ctx, short num_iter, int code_ind, bool halves
     HostCode *hc = ctx->codes[h];
     const BuiltinCode *b = find_builtin(code_ind);
     const long nf = ctx->fpga_frames;
-    const long C = std::min<long>(std::max<long>(nf, 1), fpga_chunk_frames());
+    const long C = std::min<long>(std::max<long>(nf, 1), fpga_chunk_frames(ctx));
     const bool keep = nf <= kFpgaKeepFrames;
     const long slots = keep ? std::max<long>(nf, 1) : C;
     ctx->fpga_decoded = -1;

@@ -8,8 +8,8 @@
 //      c*x = c*(x & 7)  ^  c*((x>>3 & 7) << 3)  ^  c*((x>>6) << 6)
 //
 // with the 8 + 8 + 4 partial products of the coefficient held in 5 scalar registers (loaded from a
-// 8 KB __constant__ table by one s_load_dwordx8).  ~10 VALU ops per dword, no LDS, no MFMA (a GF(256)
-// product is a table/shift-xor operation, not a dense contraction).
+// 8 KB __constant__ table by one s_load_dwordx8).  9 VALU ops per dword (5 index ops + 3 v_perm_b32 + 1 v_bitop3_b32), no LDS,
+// no MFMA (a GF(256) product is a table/shift-xor operation, not a dense contraction).
 //
 // Scalar (S = 1) paths use log/antilog tables staged in LDS:  a*b = exp[log a + log b].
 #pragma once
@@ -46,13 +46,31 @@ __device__ __forceinline__ MulTab load_multab(uint32_t c)
 
 // v_perm_b32 D, S0, S1, SEL : byte i of D = byte SEL.byte[i] of the 64-bit value {S0,S1}
 // (selector 0-3 -> S1, 4-7 -> S0).  __builtin_amdgcn_perm(S0, S1, SEL).
+// a ^ b ^ c in ONE instruction: gfx950 has no v_xor3_b32, but v_bitop3_b32 evaluates any three-input boolean function
+// (truth table 0x96 = parity); the compiler does not form it from two xors by itself.
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+
+// the three byte-select index words of a dword (they depend on the data only, not on the coefficient)
+struct Sel3 {
+    uint32_t s0, s1, s2;
+};
+__device__ __forceinline__ Sel3 gfsel(uint32_t x)
+{
+    return Sel3{x & 0x07070707u, (x >> 3) & 0x07070707u, (x >> 6) & 0x03030303u};
+}
+__device__ __forceinline__ uint32_t gfmul4_sel(const MulTab &t, const Sel3 &s)
+{
+    return xor3(__builtin_amdgcn_perm(t.t1, t.t0, s.s0), __builtin_amdgcn_perm(t.t3, t.t2, s.s1), __builtin_amdgcn_perm(t.t4, t.t4, s.s2));
+}
+// acc ^ c * x
+__device__ __forceinline__ uint32_t gfmac4_sel(uint32_t acc, const MulTab &t, const Sel3 &s)
+{
+    return xor3(acc, __builtin_amdgcn_perm(t.t1, t.t0, s.s0), __builtin_amdgcn_perm(t.t3, t.t2, s.s1)) ^ __builtin_amdgcn_perm(t.t4, t.t4, s.s2);
+}
+
 __device__ __forceinline__ uint32_t gfmul4(const MulTab &t, uint32_t x)
 {
-    const uint32_t s0 = x & 0x07070707u;
-    const uint32_t s1 = (x >> 3) & 0x07070707u;
-    const uint32_t s2 = (x >> 6) & 0x03030303u;
-    return __builtin_amdgcn_perm(t.t1, t.t0, s0) ^ __builtin_amdgcn_perm(t.t3, t.t2, s1) ^
-           __builtin_amdgcn_perm(t.t4, t.t4, s2);
+    return gfmul4_sel(t, gfsel(x));
 }
 
 __device__ __forceinline__ U4 gfmul16(const MulTab &t, const U4 &v)
@@ -64,7 +82,8 @@ __device__ __forceinline__ U4 gfmul16(const MulTab &t, const U4 &v)
 
 __device__ __forceinline__ void gfmac16(U4 &acc, const MulTab &t, const U4 &v)
 {
-    acc.x ^= gfmul4(t, v.x); acc.y ^= gfmul4(t, v.y); acc.z ^= gfmul4(t, v.z); acc.w ^= gfmul4(t, v.w);
+    acc.x = gfmac4_sel(acc.x, t, gfsel(v.x)); acc.y = gfmac4_sel(acc.y, t, gfsel(v.y));
+    acc.z = gfmac4_sel(acc.z, t, gfsel(v.z)); acc.w = gfmac4_sel(acc.w, t, gfsel(v.w));
 }
 
 // scalar product through log/antilog tables (table pointers may be LDS or constant memory)

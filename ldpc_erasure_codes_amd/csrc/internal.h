@@ -73,6 +73,37 @@ struct HostRs {
     uint8_t *d_pt = nullptr; // device copy of the parity part transposed: [n-k][k]
 };
 
+// Tuning / diagnostic knobs.  The defaults are what is shipped.  They are read from the environment
+// (LDPC_AMD_<NAME>) ONCE, by ldpc_amd_init, and can be changed per context with ldpc_amd_configure: nothing on the call path
+// looks at the process environment (a C-ABI library must not depend on getenv in a multi-threaded host).
+struct Knobs {
+    int apply_gather = 0;        // APPLY=gather: packet kernel in gather form (A/B baseline)
+    int scatter_b = 256;         // SCATTER_B: bytes of every row per packet-kernel workgroup (256, 128, 64)
+    int scatter_tiers = 2;       // SCATTER_TIERS: 1 = single tier
+    int scatter_nt = 1;          // SCATTER_NT: non-temporal row loads / stores
+    int scatter_xcd = 1;         // SCATTER_XCD: slices of a frame placed on one XCD
+    int scatter_dyn = 1;         // SCATTER_DYN: 1 LDS counter, 0 fixed stride, 2 compacted list, 3 sorted list, 4 list sorted inside 64-row windows
+    int scatter_r = 2;           // SCATTER_R: row pieces in flight per lane group, tier 1 (1, 2, 4)
+    int scatter_r2 = 4;          // SCATTER_R2: ... tier 2 (2, 3, 4)
+    int peel_wpb = 0;            // PEEL_WPB: frames per peel workgroup (0 = auto)
+    int peel_gt = -1;            // PEEL_GT: S = 1 kernel reads the code tables from global memory (-1 = auto)
+    int ml_solve = 1;            // ML_SOLVE: 1 solve schedules + solve kernel, 0 solve inside the ML kernel, 2 emit only (diagnostic)
+    int ml_dbg = 0;              // ML_DBG: diagnostic build only
+    int ml_solve_b = 128;        // ML_SOLVE_B: bytes of every row per solve-kernel workgroup
+    long long ml_arena_words = 0;   // ML_ARENA_WORDS: size of the schedule arena in 64-bit words (0 = auto)
+    int ml_threads = 0;          // ML_THREADS: threads of the ML kernel's workgroup (0 = 1024 / ML_PACK)
+    int ml_pack = 2;             // ML_PACK: ML-kernel workgroups per CU (1, 2, 3, 4): 1024 / P threads and 160 KB / P of LDS each
+    int ml_rhs = 1;              // ML_RHS: 1 the packet kernel builds the ML stage's right-hand sides while it streams (0: the solve kernel re-reads the known rows)
+    int enc_b = 128;             // ENC_B: encoder piece size (128: two workgroups per CU; 256: the decoder's plan)
+    int enc_list = 0;            // ENC_LIST: encoder streams the source rows in the order of their column degree
+    int rs_generic = 0;          // RS=generic: RS decode always through the generic LDS kernel
+    int host_pipeline = 1;       // HOST_PIPELINE: chunked upload / compute / download pipeline for large host buffers
+    long fpga_chunk = 65536;     // FPGA_CHUNK: frames per chunk of the streamed FPGA-harness run
+};
+// key: "LDPC_AMD_SCATTER_B" or "SCATTER_B" (case-insensitive); value nullptr or "" restores the default.  0 = OK, -1 = unknown key / bad value.
+int knob_set(Knobs &k, const char *key, const char *value);
+void knobs_from_env(Knobs &k);
+
 // Growable device scratch
 struct Scratch {
     void *p = nullptr;
@@ -99,7 +130,10 @@ struct ldpc_amd_ctx {
     ldpc_amd::Scratch mllist;   // [1 + nframes] int32: count, frame ids
     ldpc_amd::Scratch biglist;  // [1 + nframes] int32: frames with many steps (scatter tier 2)
     ldpc_amd::Scratch stage_in, stage_er, stage_out, stage_i32;  // host-pointer staging
+    void *pin = nullptr;        // pinned host bounce block of the small-call path
+    size_t pin_cap = 0;
     ldpc_amd::Scratch rsws;
+    ldpc_amd::Scratch rsbad;    // int: malformed blocks of the last RS decode (decoded to zeros)
     // FPGA-harness emulation state (ldpc_amd_data_in / _ldpc_erasure_decoder / _data_out)
     // The run is streamed in chunks like the FPGA's frame loop (ldpc_erasure_decoder_perf_tests.cl:52): fpga_erased holds the
     // flags of ONE chunk, fpga_stats the two running counters (+ per-frame results: of the whole run when it is short
@@ -113,6 +147,7 @@ struct ldpc_amd_ctx {
     int fpga_seed = 0;
     int fpga_binary_code[4] = {-1, -1, -1, -1};
     int sm_count = 256;
+    ldpc_amd::Knobs knobs;
     // profiling (ldpc_amd_set_profiling): event pairs per kernel kind
     bool profiling = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[LDPC_AMD_PROF_KINDS];

@@ -606,6 +606,8 @@ struct ScatterArgs {
     int lds_acc, lds_tgt, lds_invc, lds_lvlend, lds_rowctr, lds_mt, lds_soc, lds_chk;
     int lds_soc_bytes;        // size of the row-kind / row-list region
     int enc_list;             // encode: stream the source rows in DevCode::enc_order
+    int dbg;                  // diagnostic build only (-DLDPC_AMD_MLDBG): 32768 = tier 1 also takes the frames with more than tcap steps,
+                              // cut off at tcap steps (WRONG bytes: prices the first pass of a level-split tier 2)
 };
 
 __device__ __forceinline__ MulTab lds_multab(const uint32_t *mt, uint32_t c)
@@ -625,6 +627,35 @@ __device__ __forceinline__ void lds_xor16(unsigned char *p, const U4 &v, int h)
     unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
     __hip_atomic_fetch_xor(q + h, h ? hi : lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __hip_atomic_fetch_xor(q + (1 - h), h ? lo : hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Split-half layout of a 16-bytes-per-lane accumulator slice (G lanes x 16 B): the G low halves first (8 B per lane), then
+// the G high halves.  One ds_xor_b64 then covers 8 G contiguous bytes -- every bank once per 16 lanes -- without the per-lane
+// choice of which half goes first (four v_cndmask_b32 per accumulate in the interleaved layout).  a_lo / a_hi: LDS byte addresses.
+__device__ __forceinline__ void lds_xor16_split(uint32_t a_lo, uint32_t a_hi, const U4 &v)
+{
+    typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+    const unsigned long long lo = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
+    const unsigned long long hi = (unsigned long long)v.z | ((unsigned long long)v.w << 32);
+    __hip_atomic_fetch_xor(reinterpret_cast<lds_u64 *>((uintptr_t)a_lo), lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_xor(reinterpret_cast<lds_u64 *>((uintptr_t)a_hi), hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ U4 lds_read16_split(const unsigned char *slice, int gl, int half_bytes)
+{
+    const unsigned long long lo = *reinterpret_cast<const unsigned long long *>(slice + gl * 8);
+    const unsigned long long hi = *reinterpret_cast<const unsigned long long *>(slice + half_bytes + gl * 8);
+    return U4{(uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32)};
+}
+// multiply table of a coefficient from its LDS byte address
+__device__ __forceinline__ MulTab lds_multab_at(uint32_t addr)
+{
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+    const u32x4 q = *reinterpret_cast<const lds_u32x4 *>((uintptr_t)addr);
+    MulTab t;
+    t.t0 = q.x; t.t1 = q.y; t.t2 = q.z; t.t3 = q.w; t.t4 = *reinterpret_cast<const lds_u32 *>((uintptr_t)(addr + 16));
+    return t;
 }
 
 // the same with the two 8-byte targets given as LDS byte addresses (first instruction -> a1, second -> a2; a1 is the lane's
@@ -676,16 +707,32 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     const int g = lane / LPR, gl = lane % LPR, h = (lane >> 3) & 1;
     const int gbase = lane & ~(LPR - 1);
 
-    unsigned char *acc = smem + a.lds_acc;
+    // LDS map of the packet kernels (scatter_set_lds): the 8 KB of multiply tables FIRST, the accumulators behind them, the small
+    // tables behind those.  With the tables at LDS address 0 an edge word (coef << 24 | LDS address of the accumulator slice) gives
+    // the table address with ONE shift (coef * 32 = word >> 19: LDS addresses stay below 2^18) and the two accumulate addresses
+    // with one and-or each.
+    constexpr int kMtOff = 0, kAccOff = 8192;
+    typedef __attribute__((address_space(3))) unsigned char lds_u8;
+    // The dynamic LDS of these kernels starts at LDS address 0 (they use no static LDS).  Checked, not just assumed: a frame is
+    // left undecoded -- every parity test fails -- if a static __shared__ variable ever sneaks in front of it.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_u8 *)(smem);
+    if (lds0 != 0u) return;
+    __builtin_assume(lds0 == 0u);
+    const uint32_t accbase = (uint32_t)kAccOff;
+    unsigned char *acc = smem + kAccOff;
     uint16_t *tgt = reinterpret_cast<uint16_t *>(smem + a.lds_tgt);
     uint8_t *invc = smem + a.lds_invc;
     uint16_t *lvlend = reinterpret_cast<uint16_t *>(smem + a.lds_lvlend);
-    uint32_t *mt = reinterpret_cast<uint32_t *>(smem + a.lds_mt);
+    uint32_t *mt = reinterpret_cast<uint32_t *>(smem + kMtOff);
     uint8_t *rk = smem + a.lds_soc;  // row kinds, [n]
     uint16_t *soc = reinterpret_cast<uint16_t *>(smem + a.lds_chk);  // check -> slot of the step that uses it, 0xFFFF
 
     LDPC_STAMP_INIT;
+#ifdef LDPC_AMD_MLDBG
+    const int nsteps = a.static_sched ? cd.m : ((a.dbg & 32768) ? min((int)a.sched_hdr[2 * f], a.nslots) : (int)a.sched_hdr[2 * f]);
+#else
     const int nsteps = a.static_sched ? cd.m : (int)a.sched_hdr[2 * f];
+#endif
     const int nlev = a.static_sched ? cd.enc_nlevels : (int)a.sched_hdr[2 * f + 1];
     const uint32_t *gs = a.static_sched ? cd.enc_steps : a.sched_steps + f * cd.m;
     const uint16_t *gle = a.static_sched ? cd.enc_lvlend : a.sched_lvlend + f * (cd.m + 1);
@@ -726,7 +773,11 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         }
     }
     for (int i = tid; i < 2048; i += nthr) mt[i] = c_mul3[i];
+#ifdef LDPC_AMD_MLDBG
+    for (int i = tid; i <= nlev; i += nthr) lvlend[i] = (uint16_t)min((int)gle[i], nsteps);
+#else
     for (int i = tid; i <= nlev; i += nthr) lvlend[i] = gle[i];
+#endif
     if (!a.static_sched)   // (the encoder's lists are in slot form already: it has no check -> slot table)
         for (int i = tid; i < (cd.m + 1) / 2; i += nthr) reinterpret_cast<uint32_t *>(soc)[i] = 0xFFFFFFFFu;
     if (tid < 2) reinterpret_cast<int *>(smem + a.lds_rowctr)[tid] = 0;   // [0] row-batch counter of the streaming phase, [1] received rows
@@ -778,11 +829,15 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     // rows in index order a pass takes max-over-four turns: 2.4 for 1.3 edges per row at 10 % erasures), and the rows
     // that feed nothing come last and skip the multiply set-up altogether.
     const bool sorted_mode = a.dyn_rows == 3 && n <= EPT * nthr && !a.static_sched && cdw <= 16;
+    // Windowed sorted list (a.dyn_rows == 4): the same ordering INSIDE windows of 64 consecutive rows (the rows one wavefront
+    // of the set-up holds), windows in index order: the pieces of a pass still take about the same number of turns, and a pass
+    // stays inside a 64 KB stretch of the frame instead of hopping all over it (what the global order lost to).
+    const bool win_mode = a.dyn_rows == 4 && n <= EPT * nthr && !a.static_sched && cdw <= 16;
     // Encoder (static schedule): the list is the code's source symbols in the order of their column degree, prepared by the
     // host (DevCode::enc_order) -- same effect as the sorted mode, no per-frame work.  Measured slower than index order (the
     // list look-ups and the lost DRAM locality cost more than the balanced turns save): only with LDPC_AMD_ENC_LIST=1.
     const bool static_list = a.static_sched && a.enc_list && a.lds_soc_bytes >= 2 * a.in_rows;
-    const bool list_mode = ((a.dyn_rows == 2 || sorted_mode) && n <= EPT * nthr && !a.static_sched) || static_list;
+    const bool list_mode = ((a.dyn_rows == 2 || sorted_mode || win_mode) && n <= EPT * nthr && !a.static_sched) || static_list;
     if (static_list) {
         for (int i = tid; i < a.in_rows; i += nthr) rlist[i] = cd.enc_order[i];
         __syncthreads();
@@ -797,8 +852,8 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
             kd[u] = (j < n) ? (uint32_t)rk[j] : 0u;
             ec[u] = 0;
         }
-        if (sorted_mode) {
-            if (tid < 34) bins[tid] = 0;
+        if (sorted_mode || win_mode) {
+            if (tid < 34 && sorted_mode) bins[tid] = 0;
 #pragma unroll
             for (int u = 0; u < EPT; u++) {
                 const int j = tid + u * nthr;
@@ -810,6 +865,13 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
                     }
                     ec[u] = c;
                 }
+            }
+        }
+        if (win_mode) {   // received rows per window (window u * nw + wave = the rows this wavefront holds in slot u)
+#pragma unroll
+            for (int u = 0; u < EPT; u++) {
+                const int c = __popcll(__ballot(kd[u] == 1u));
+                if (lane == 0) bins[u * nw + wave] = c;
             }
         }
         __syncthreads();
@@ -833,7 +895,20 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         for (int u = 0; u < EPT; u++) {
             const int j = tid + u * nthr;
             const bool recv = kd[u] == 1u;
-            if (sorted_mode) {
+            if (win_mode) {
+                // start of this window in the list = received rows of the windows before it (at most 64 windows: one per lane)
+                const int w = u * nw + wave;
+                int base = (lane < w) ? bins[lane] : 0;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) base += __shfl_xor(base, d);
+                for (int c = cdw; c >= 0; c--) {   // most edges first inside the window
+                    const bool mine = recv && ec[u] == (uint32_t)c;
+                    const uint64_t mask = __ballot(mine);
+                    if (mine) rlist[base + __popcll(mask & ((1ull << lane) - 1ull))] = (uint16_t)j;
+                    base += __popcll(mask);
+                }
+                if (u == EPT - 1 && wave == nw - 1 && lane == 0) *nrecv_p = base;   // the last window ends the list
+            } else if (sorted_mode) {
                 for (int c = 0; c <= cdw; c++) {
                     const bool mine = recv && ec[u] == (uint32_t)c;
                     const uint64_t mask = __ballot(mine);
@@ -871,9 +946,15 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
 
     // multiplies v into the accumulators of the steps that symbol j feeds: ew = the symbol's list, entry t held by
     // lane (t % LPR) of the group, 0xFFFFFFFF = no entry.  Every group walks the set bits of its own validity mask.
-    // (entries are in the form to_slots leaves them in: accumulator byte offset | coef << 24; a lane's own 16 bytes of the
-    // accumulator, halves in the bank-friendly order, are OR-ed in: the offset is a multiple of B, the lane's part is below B)
-    const uint32_t lane_a = (uint32_t)(gl * 16 + h * 8), lane_b = (uint32_t)(gl * 16 + (1 - h) * 8);
+    // (entries are in the form to_slots leaves them in: LDS address of the accumulator slice | coef << 24; a lane's own two
+    // 8-byte halves -- split-half layout -- are OR-ed in: the slice address is a multiple of B, the lane's part is below B)
+    // LPR == 16 (256-byte pieces): split-half layout, no per-lane choice.  Narrower pieces put two or more lane groups -- different
+    // accumulators -- into every 16 lanes, and their 8 LPR contiguous bytes would meet on the same banks: those keep the interleaved
+    // layout in which lanes 8-15 of every 16 issue their halves in the opposite order (measured: encoder 4.08 -> 4.24 ms with the
+    // split layout at LPR = 8).
+    constexpr bool kSplit = LPR == 16;
+    const uint32_t lane_a = kSplit ? (uint32_t)(gl * 8) : (uint32_t)(gl * 16 + h * 8);
+    const uint32_t lane_b = kSplit ? (uint32_t)(B / 2 + gl * 8) : (uint32_t)(gl * 16 + (1 - h) * 8);
     auto scatter = [&](const U4 &v, const uint32_t (&ew)[KQ]) {
 #pragma unroll
         for (int q = 0; q < KQ; q++) {
@@ -885,9 +966,11 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
                 gm &= gm - 1u;
                 const uint32_t ed = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + u) << 2, (int)ew[q]);
                 if (go) {
-                    const U4 prod = gfmul16(lds_multab(mt, ed >> 24), v);
-                    const uint32_t ao = ed & 0x00FFFFFFu;
-                    lds_xor16_at(ao | lane_a, ao | lane_b, prod, h);   // (the accumulators start the LDS: lds_acc == 0, no static LDS)
+                    const U4 prod = gfmul16(lds_multab_at(ed >> 19), v);   // coef * 32: the tables start the LDS
+                    // (two different masks -- both clear the coefficient byte, addresses are below 2^18 -- so that each address is
+                    // one v_and_or_b32 instead of a shared v_and_b32 plus two v_or_b32)
+                    if (kSplit) lds_xor16_split((ed & 0x00FFFFFFu) | lane_a, (ed & 0x007FFFFFu) | lane_b, prod);
+                    else lds_xor16_at((ed & 0x00FFFFFFu) | lane_a, (ed & 0x007FFFFFu) | lane_b, prod, h);
                 }
             }
         }
@@ -902,12 +985,12 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         for (int q = 0; q < KQ; q++) {
             const uint32_t w = ew[q];
             if (!translate) {   // encoder: the static lists hold (slot * 128 | coef << 24): the form of its default 128-byte pieces
-                if (B > 128) ew[q] = (w != 0xFFFFFFFFu) ? (((w & 0x00FFFFFFu) * (uint32_t)(B / 128)) | (w & 0xFF000000u)) : 0xFFFFFFFFu;
-                else if (B < 128) ew[q] = (w != 0xFFFFFFFFu) ? (((w & 0x00FFFFFFu) / (uint32_t)(128 / B)) | (w & 0xFF000000u)) : 0xFFFFFFFFu;
+                const uint32_t so = (B >= 128) ? (w & 0x00FFFFFFu) * (uint32_t)(B / 128 > 0 ? B / 128 : 1) : (w & 0x00FFFFFFu) / (uint32_t)(B < 128 ? 128 / B : 1);
+                ew[q] = (w != 0xFFFFFFFFu) ? ((accbase + so) | (w & 0xFF000000u)) : 0xFFFFFFFFu;
                 continue;
             }
             const uint32_t s = soc[w == 0xFFFFFFFFu ? 0u : (w & 0xFFFFu)];
-            ew[q] = (w != 0xFFFFFFFFu && s != 0xFFFFu && s != own) ? ((s * (uint32_t)B) | ((w & 0x00FF0000u) << 8)) : 0xFFFFFFFFu;
+            ew[q] = (w != 0xFFFFFFFFu && s != 0xFFFFu && s != own) ? ((accbase + s * (uint32_t)B) | ((w & 0x00FF0000u) << 8)) : 0xFFFFFFFFu;
         }
     };
 
@@ -1066,7 +1149,8 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
                 }
                 if (s < s1) {
                     const int t = tgt[s];
-                    const U4 a16 = *reinterpret_cast<const U4 *>(acc + (size_t)s * B + gl * 16);
+                    const U4 a16 = kSplit ? lds_read16_split(acc + (size_t)s * B, gl, B / 2)
+                                          : *reinterpret_cast<const U4 *>(acc + (size_t)s * B + gl * 16);
                     val = gfmul16(lds_multab(mt, invc[s]), a16);
                     stream_store16<NT>(out_row(t), val);
                 }
@@ -1102,7 +1186,11 @@ __global__ __launch_bounds__(1024, WPE) void ldpc_scatter_kernel(ScatterArgs a)
         f = blockIdx.x / a.nslices;
         sl = (int)(blockIdx.x % a.nslices);
     }
+#ifdef LDPC_AMD_MLDBG
+    if (!a.static_sched && (int)a.sched_hdr[2 * f] > a.tcap && !(a.dbg & 32768)) return;
+#else
     if (!a.static_sched && (int)a.sched_hdr[2 * f] > a.tcap) return;
+#endif
     scatter_frame<LPR, R, NT, INPLACE>(a, smem, f, sl);
 }
 
@@ -1368,23 +1456,21 @@ static int scatter_tail_bytes(const DevCode &cd, ScatterPlan &p)
     p.o_tgt = off; off += align_up(2 * cd.m, 16);
     p.o_invc = off; off += align_up(cd.m, 16);
     p.o_lvl = off; off += align_up(2 * (cd.m + 2), 16);
-    p.o_ctr = off; off += 160;  // row-batch counter of the streaming phase, received-row count, bins of the sorted list
-    p.o_mt = off; off += 8192;
+    p.o_ctr = off; off += 288;  // row-batch counter of the streaming phase, received-row count, bins of the sorted list / window counts
+    p.o_mt = off;               // (the multiply tables start the LDS: counted by scatter_lds_bytes, not here)
     p.o_soc = off; off += align_up(2 * cd.n, 16);  // row kinds (u8), later the list of received rows (u16)
     p.soc_bytes = align_up(2 * cd.n, 16);
     p.o_chk = off; off += align_up(2 * (cd.m + 2), 16);  // check -> slot
     return off;
 }
 
-static ScatterPlan plan_scatter(const DevCode &cd, int S)
+static ScatterPlan plan_scatter(const Knobs &kn, const DevCode &cd, int S)
 {
     ScatterPlan p;
     if ((uint64_t)cd.n * (uint64_t)S >= (1ull << 32) || S >= (1 << 24) || cd.n >= (1 << 16)) return p;   // the kernel addresses a frame with 32-bit offsets (24-bit multiplies)
-    int B = 256;
-    const char *env_b = getenv("LDPC_AMD_SCATTER_B");  // A/B knob: bytes of every row per workgroup
-    if (env_b && (atoi(env_b) == 128 || atoi(env_b) == 64)) B = atoi(env_b);
+    int B = kn.scatter_b;  // A/B knob: bytes of every row per workgroup
     while (B > 16 && (S % B) != 0) B >>= 1;
-    const int tail = scatter_tail_bytes(cd, p);
+    const int tail = scatter_tail_bytes(cd, p) + 8192;   // + the multiply tables in front of the accumulators
     while (B > 16 && cd.m * B + tail > 156 * 1024) B >>= 1;
     if (cd.m * B + tail > kLdsMax) return p;
     p.lpr = B / 16;
@@ -1392,8 +1478,7 @@ static ScatterPlan plan_scatter(const DevCode &cd, int S)
     p.lds2 = cd.m * B + tail;
     // Two workgroups per CU (each half of the 160 KB) hide one workgroup's set-up and level phase behind the
     // other's streaming phase: possible when the accumulators of the typical frame fit in half the LDS.
-    const char *env = getenv("LDPC_AMD_SCATTER_TIERS");
-    const bool allow = !(env && atoi(env) == 1);
+    const bool allow = kn.scatter_tiers != 1;
     const int half = kLdsMax / 2;
     int tcap = (half - tail) / B;
     if (allow && p.lpr >= 8 && tcap >= cd.m / 4 && tcap < cd.m) {
@@ -1409,10 +1494,11 @@ static ScatterPlan plan_scatter(const DevCode &cd, int S)
 
 static void scatter_set_lds(ScatterArgs &sa, const ScatterPlan &p, int nacc)
 {
-    const int base = align_up(nacc * 16 * p.lpr, 16);
-    sa.lds_acc = 0;   // (the streaming loop relies on it: accumulator offsets are used as LDS addresses)
+    // [0, 8192) multiply tables | [8192, ...) accumulators | small tables   (kMtOff / kAccOff of scatter_frame)
+    const int base = 8192 + align_up(nacc * 16 * p.lpr, 16);
+    sa.lds_acc = 8192;
     sa.lds_tgt = base + p.o_tgt; sa.lds_invc = base + p.o_invc; sa.lds_lvlend = base + p.o_lvl;
-    sa.lds_rowctr = base + p.o_ctr; sa.lds_mt = base + p.o_mt; sa.lds_soc = base + p.o_soc; sa.lds_chk = base + p.o_chk;
+    sa.lds_rowctr = base + p.o_ctr; sa.lds_mt = 0; sa.lds_soc = base + p.o_soc; sa.lds_chk = base + p.o_chk;
     sa.lds_soc_bytes = p.soc_bytes;
 }
 
@@ -1420,12 +1506,10 @@ template <int LPR, int R>
 static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterArgs sa, const int32_t *big_list)
 {
     constexpr int THREADS = (LPR >= 8) ? 1024 : (LPR >= 2 ? 512 : 256);
-    const char *env_nt = getenv("LDPC_AMD_SCATTER_NT");
-    const bool nt = env_nt ? atoi(env_nt) != 0 : true;
-    const char *env_x = getenv("LDPC_AMD_SCATTER_XCD");
-    const char *env_d = getenv("LDPC_AMD_SCATTER_DYN");
-    sa.dyn_rows = env_d ? atoi(env_d) : 1;
-    sa.xcd_map = env_x ? atoi(env_x) : 1;  // measured: 3.12 vs 3.22 ms once the set-up was shortened; =0 switches it off
+    const Knobs &kn = ctx->knobs;
+    const bool nt = kn.scatter_nt != 0;
+    sa.dyn_rows = kn.scatter_dyn;
+    sa.xcd_map = kn.scatter_xcd;  // measured: 3.12 vs 3.22 ms once the set-up was shortened; =0 switches it off
     const dim3 grid((unsigned)(sa.nframes * sa.nslices));
     // tier 1
     sa.tcap = p.tcap; sa.nslots = p.tcap; sa.big_list = nullptr;
@@ -1452,14 +1536,13 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
     }
 #undef LDPC_SCATTER_T1
     LDPC_HIP_TRY(ctx, hipGetLastError());
-    if (p.two_tier && big_list) {
+    if (p.two_tier && big_list && !(sa.dbg & 32768)) {
         sa.tcap = sa.code.m; sa.nslots = sa.code.m; sa.big_list = big_list;
         scatter_set_lds(sa, p, sa.code.m);
         const dim3 g2((unsigned)std::min<int64_t>(sa.nframes * sa.nslices, ctx->sm_count));
         // tier 2 runs one workgroup per CU (4 waves per SIMD, 128 VGPRs each): four row pieces in flight per lane group
         // instead of two make up for part of the missing occupancy (cfg 3: 4.42 -> 4.19 ms); LDPC_AMD_SCATTER_R2=2 restores two
-        const char *env_r2 = getenv("LDPC_AMD_SCATTER_R2");
-        const int r2 = LPR == 16 ? (env_r2 ? atoi(env_r2) : 4) : 0;
+        const int r2 = LPR == 16 ? kn.scatter_r2 : 0;
 #define LDPC_SCATTER_T2_R(RV, NTV, IPV)                                                                      \
     {                                                                                                        \
         auto kfn = ldpc_scatter_big_kernel<LPR, RV, NTV, IPV>;                                               \
@@ -1481,8 +1564,7 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
 
 static int launch_scatter(ldpc_amd_ctx *ctx, const ScatterPlan &p, const ScatterArgs &sa, const int32_t *big_list)
 {
-    const char *env_r = getenv("LDPC_AMD_SCATTER_R");
-    const int rr = env_r ? atoi(env_r) : 2;
+    const int rr = ctx->knobs.scatter_r;
     switch (p.lpr) {
         case 16: return rr == 4 ? launch_scatter_lpr<16, 4>(ctx, p, sa, big_list) : (rr == 1 ? launch_scatter_lpr<16, 1>(ctx, p, sa, big_list) : launch_scatter_lpr<16, 2>(ctx, p, sa, big_list));
         case 8: return rr == 4 ? launch_scatter_lpr<8, 4>(ctx, p, sa, big_list) : launch_scatter_lpr<8, 2>(ctx, p, sa, big_list);
@@ -1522,10 +1604,10 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
 
     // packet path: scatter kernel (rows read once, accumulators in LDS) unless the code's columns are too
     // heavy for the padded per-source lists, or LDPC_AMD_APPLY=gather asks for the gather kernel (A/B runs)
-    const char *apply_env = getenv("LDPC_AMD_APPLY");
-    const bool want_gather = apply_env && strcmp(apply_env, "gather") == 0;
+    const Knobs &kn = ctx->knobs;
+    const bool want_gather = kn.apply_gather != 0;
     ScatterPlan plan{};
-    if (!fused && !d.flags_only && !want_gather && cd.maxcoldeg <= 16) plan = plan_scatter(cd, d.S);
+    if (!fused && !d.flags_only && !want_gather && cd.maxcoldeg <= 16) plan = plan_scatter(kn, cd, d.S);
     const bool use_scatter = plan.lpr > 0;
     if (d.inplace && !use_scatter) return set_error(ctx, LDPC_AMD_EUNSUP, "in-place decode needs the scatter kernel");
 
@@ -1537,8 +1619,8 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     if (L.total > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "code too large for LDS (%d bytes)", L.total);
     {
         int best = 0;
-        const char *env_w = getenv("LDPC_AMD_PEEL_WPB");   // diagnostic: cap the wavefronts (= frames) per workgroup
-        const int wcap = env_w ? std::max(1, std::min(16, atoi(env_w))) : 16;
+        const bool env_w = kn.peel_wpb > 0;   // diagnostic: cap the wavefronts (= frames) per workgroup
+        const int wcap = env_w ? std::max(1, std::min(16, kn.peel_wpb)) : 16;
         for (int w = 1; w <= wcap; w++) {
             const PeelLds t = make_peel_lds(cd, fused, w);
             if (t.total > kLdsMax) break;
@@ -1547,8 +1629,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         }
         // S = 1, long batch: with the code tables left in global memory more frames fit on a CU.  Worth it when the
         // batch is several rounds deep anyway (a single round is latency bound and prefers the LDS tables).
-        const char *env_gt = getenv("LDPC_AMD_PEEL_GT");
-        if (fused && !env_w && !(env_gt && atoi(env_gt) == 0)) {
+        if (fused && !env_w && kn.peel_gt != 0) {
             int bestg = 0, wg = 1;
             PeelLds Lg = L;
             for (int w = 1; w <= 16; w++) {
@@ -1559,7 +1640,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             }
             const bool deep = d.nframes >= (int64_t)3 * best * ctx->sm_count;
             // measured: (4080,3060) 7 -> 11 frames per CU: -18 %, (4000,2000) 5 -> 8: -15 %, (2040,1530) 16 -> 21: +12 % (slower)
-            if ((env_gt && atoi(env_gt) == 1) || (deep && bestg * 20 >= best * 29)) { gt = true; wpb = wg; L = Lg; }
+            if (kn.peel_gt == 1 || (deep && bestg * 20 >= best * 29)) { gt = true; wpb = wg; L = Lg; }
         }
     }
 
@@ -1615,6 +1696,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             ScatterArgs sa{};
             sa.code = cd; sa.S = d.S; sa.nslices = plan.nslices; sa.nframes = nf; sa.sym = d.sym; sa.erased = d.erased; sa.out = d.out;
             sa.in_rows = cd.n; sa.static_sched = 0; sa.inplace = d.inplace;
+            sa.dbg = kn.ml_dbg;
             sa.sched_hdr = pa.sched_hdr; sa.sched_steps = pa.sched_steps; sa.sched_lvlend = pa.sched_lvlend;
             sa.sched_invc = pa.sched_invc;
             ev = prof_begin(ctx);
@@ -1660,9 +1742,14 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         ma.lds_A = off;
         if (off > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "ML stage: LDS need %d bytes", off);
         if (cd.m > 4096) return set_error(ctx, LDPC_AMD_EUNSUP, "ML stage: more than 4096 checks (%d)", cd.m);   // 12-bit row fields of the pivot key
-        ma.capA = (kLdsMax - off) & ~15;
-        const int total = kLdsMax;
-        int grid = (int)std::min<int64_t>(nf, (int64_t)ctx->sm_count);
+        // ML_PACK = P workgroups per CU (1024 / P threads, 160 KB / P of LDS each): the factorisation is bound by the instructions
+        // all wavefronts of a workgroup issue per column, not by the work in a column, so P small workgroups -- P systems per CU,
+        // their matrices in the global scratch (L2) when they do not fit the LDS share -- issue P times fewer of them per system
+        const int pack = std::max(1, std::min(4, kn.ml_pack));
+        const int total = std::max(off + 256, (kLdsMax / pack) & ~255);
+        if (total > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "ML stage: LDS need %d bytes", total);
+        ma.capA = (total - off) & ~15;
+        int grid = (int)std::min<int64_t>(nf, (int64_t)ctx->sm_count * pack);
         const size_t perA = (size_t)cd.m * maxrow, perR = fused ? 0 : (size_t)cd.m * d.S;
         if ((rc = scratch_reserve(ctx, ctx->mlws, (perA + perR) * grid + 256))) return rc;
         // work counters: [0] frame hand-out counter, [2..3] arena bump pointer (u64), [4] task counter of the solve kernel.  They
@@ -1675,13 +1762,11 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         // packets: the ML kernel factors every residual system on bytes and emits a solve schedule (64-bit ops grouped by
         // dependency level) into an arena; ldpc_ml_solve_kernel then runs the schedules on LDS-resident row slices.
         // Frames whose schedule does not fit the arena are solved inside the ML kernel (same bytes, slower).
-        const char *env_sv = getenv("LDPC_AMD_ML_SOLVE");
-        ma.use_solve = (!fused && !(env_sv && atoi(env_sv) == 0)) ? 1 : 0;
-        if (const char *e = getenv("LDPC_AMD_ML_DBG")) ma.dbg = atoi(e);
+        ma.use_solve = (!fused && kn.ml_solve != 0) ? 1 : 0;
+        ma.dbg = kn.ml_dbg;
         int solve_b = 0;
         if (ma.use_solve) {
-            solve_b = 128;
-            if (const char *e = getenv("LDPC_AMD_ML_SOLVE_B")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64 || v == 128) solve_b = v; }   // A/B knob
+            solve_b = kn.ml_solve_b;   // A/B knob
             while (solve_b > 16 && (d.S % solve_b) != 0) solve_b >>= 1;
             const int tail_sv = align_up(4 * (2 * cd.m + 6), 16) + 8192 + 16 + 4 * kMlClasses;
             while (solve_b > 16 && cd.m * solve_b + tail_sv > 79 * 1024) solve_b >>= 1;
@@ -1689,10 +1774,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         }
         if (ma.use_solve) {
             size_t words = std::min<size_t>(std::max<size_t>((size_t)nf * 8192, (size_t)1 << 21), (size_t)1 << 27);   // 64 KB per frame; 16 MB ... 1 GB
-            if (const char *e = getenv("LDPC_AMD_ML_ARENA_WORDS")) {   // test knob: a small arena makes some frames fall back
-                const long long v = atoll(e);
-                if (v >= 1024) words = (size_t)v;
-            }
+            if (kn.ml_arena_words >= 1024) words = (size_t)kn.ml_arena_words;   // test knob: a small arena makes some frames fall back
             if ((rc = scratch_reserve(ctx, ctx->mlops, words * 8)) || (rc = scratch_reserve(ctx, ctx->mlrec, (size_t)nf * 32))) return rc;
             ma.ops = (unsigned long long *)ctx->mlops.p; ma.ops_cap = words;
             ma.ops_head = (unsigned long long *)(ma.work + 2);
@@ -1701,18 +1783,14 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             if ((rc = scratch_reserve(ctx, ctx->mlrec, (size_t)nf * 32))) return rc;
             ma.rec = (uint32_t *)ctx->mlrec.p;   // the fall-back flag is written in either case
         }
-        int ml_threads = 1024;
-        if (const char *e = getenv("LDPC_AMD_ML_THREADS")) {
-            const int v = atoi(e);
-            if (v >= 256 && v <= 1024 && (v % 64) == 0) ml_threads = v;
-        }
+        const int ml_threads = kn.ml_threads > 0 ? kn.ml_threads : std::max(256, (1024 / pack) & ~63);
         auto kfn = ldpc_ml_kernel;
         LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(kfn)));
         ctx->prof_names[LDPC_AMD_PROF_ML] = "ldpc_ml_kernel";
         hipEvent_t ev = prof_begin(ctx);
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(ml_threads), (size_t)total, ctx->stream, ma);
         LDPC_HIP_TRY(ctx, hipGetLastError());
-        if (ma.use_solve && !(env_sv && atoi(env_sv) == 2)) {   // =2: diagnostic, schedules emitted but not run (timing of the factor part)
+        if (ma.use_solve && kn.ml_solve != 2) {   // =2: diagnostic, schedules emitted but not run (timing of the factor part)
             MlSolveArgs sv{};
             sv.code = cd; sv.S = d.S; sv.nslices = d.S / solve_b; sv.nframes = nf; sv.ml_list = ma.ml_list; sv.rec = ma.rec; sv.ops = ma.ops;
             sv.out = d.out; sv.work = ma.work + 4;
@@ -1755,30 +1833,29 @@ int launch_encode(ldpc_amd_ctx *ctx, const DevCode &cd, int S, int64_t nframes, 
         return launch_decode(ctx, d);
     }
     if (S % 16) return set_error(ctx, LDPC_AMD_EUNSUP, "S must be 1 or a multiple of 16 (got %d)", S);
-    const char *apply_env = getenv("LDPC_AMD_APPLY");
-    if (!(apply_env && strcmp(apply_env, "gather") == 0) && cd.maxcoldeg <= 16) {
+    const Knobs &kn = ctx->knobs;
+    if (!kn.apply_gather && cd.maxcoldeg <= 16) {
         // scatter form with the static schedule: source rows read once, all m accumulators in LDS
-        ScatterPlan plan = plan_scatter(cd, S);
+        ScatterPlan plan = plan_scatter(kn, cd, S);
         if (plan.lpr > 0) {
             plan.two_tier = false; plan.tcap = cd.m; plan.lds1 = plan.lds2;
             // The encoder needs all m accumulators (every check is a step), which at 256-byte row pieces fills the LDS with
             // ONE workgroup per CU.  With 128-byte pieces and the tables the static schedule does not need left out (check ->
             // slot table, received-row list) two workgroups fit, and one streams while the other runs its 27 levels.
-            const char *env_eb = getenv("LDPC_AMD_ENC_B");
-            const int eb = env_eb ? atoi(env_eb) : 128;
+            const int eb = kn.enc_b;
             if (plan.lpr == 16 && eb == 128 && (S % 128) == 0) {
                 ScatterPlan q = plan;
                 int off = 0;
                 q.o_tgt = off; off += align_up(2 * cd.m, 16);
                 q.o_invc = off; off += align_up(cd.m, 16);
                 q.o_lvl = off; off += align_up(2 * (cd.m + 2), 16);
-                q.o_ctr = off; off += 160;
-                q.o_mt = off; off += 8192;
+                q.o_ctr = off; off += 288;
+                q.o_mt = off;                // (the tables sit in front of the accumulators: added to the total below)
                 q.o_soc = off; off += align_up(2 * cd.k, 16) >= cd.n ? align_up(2 * cd.k, 16) : align_up(cd.n, 16);   // row kinds (u8), then the source-row list (u16 [k])
                 q.soc_bytes = align_up(2 * cd.k, 16) >= cd.n ? align_up(2 * cd.k, 16) : align_up(cd.n, 16);
                 q.o_chk = off;                               // unused in static mode
-                if (cd.m * 128 + off <= kLdsMax / 2) {
-                    q.lpr = 8; q.nslices = S / 128; q.lds1 = q.lds2 = cd.m * 128 + off;
+                if (8192 + cd.m * 128 + off <= kLdsMax / 2) {
+                    q.lpr = 8; q.nslices = S / 128; q.lds1 = q.lds2 = 8192 + cd.m * 128 + off;
                     q.two_tier = true;    // (only selects the 8-waves-per-SIMD instantiation; tcap = m: no frame goes to tier 2)
                     plan = q;
                 }
@@ -1786,8 +1863,7 @@ int launch_encode(ldpc_amd_ctx *ctx, const DevCode &cd, int S, int64_t nframes, 
             ScatterArgs sa{};
             sa.code = cd; sa.S = S; sa.nslices = plan.nslices; sa.nframes = nframes; sa.sym = src; sa.erased = nullptr; sa.out = cw;
             sa.in_rows = cd.k; sa.static_sched = 1;
-            const char *env_el = getenv("LDPC_AMD_ENC_LIST");
-            sa.enc_list = (env_el && atoi(env_el) == 1) ? 1 : 0;   // measured slower (4.62 vs 4.14 ms): off unless asked for
+            sa.enc_list = kn.enc_list;   // measured slower (4.62 vs 4.14 ms): off unless asked for
             return launch_scatter(ctx, plan, sa, nullptr);
         }
     }
@@ -1804,6 +1880,7 @@ int launch_rs_decode(ldpc_amd_ctx *ctx, const HostRs &rs, int S, int64_t nblocks
 {
     if (nblocks <= 0) return LDPC_AMD_OK;
     const int R = rs.n - rs.k;
+    int rc0;
     RsArgs a{};
     a.n = rs.n; a.k = rs.k; a.S = S; a.nblocks = nblocks; a.pt = rs.d_pt; a.recv_idx = idx; a.recv_val = val; a.msg = msg;
     int off = 0;
@@ -1816,8 +1893,37 @@ int launch_rs_decode(ldpc_amd_ctx *ctx, const HostRs &rs, int S, int64_t nblocks
     a.lds_ex = off; off += 512;
     a.lds_misc = off; off += 16;
     if (off > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "RS decode: LDS need %d bytes", off);
-    const char *rs_env = getenv("LDPC_AMD_RS");
-    if (S == 1 && R <= 32 && rs.k <= 256 && !(rs_env && strcmp(rs_env, "generic") == 0)) {
+    const bool rs_generic = ctx->knobs.rs_generic != 0;
+    // malformed blocks (positions not ascending / >= n) are decoded to zeros and counted (ldpc_amd_rs_bad_blocks)
+    if ((rc0 = scratch_reserve(ctx, ctx->rsbad, 64))) return rc0;
+    a.bad = (int *)ctx->rsbad.p;
+    LDPC_HIP_TRY(ctx, hipMemsetAsync(a.bad, 0, sizeof(int), ctx->stream));
+    if (S >= 256 && (S % 256) == 0 && R <= 32 && rs.k <= 256 && !rs_generic) {
+        // packets: one wavefront per (block, slice), M^-1 in registers, rows streamed once, accumulators in registers
+        const int vw = (S % 1024) == 0 ? 4 : ((S % 512) == 0 ? 2 : 1);
+        const int nslices = S / (256 * vw);
+        RsPkLds L{};
+        int o = 0;
+        L.pt = o; o += align_up(R * rs.k, 16);
+        L.lg = o; o += 256;
+        L.mtl = o; o += 8192;
+        L.wave0 = o; L.wstride = 512 + 256 + 32;
+        const int nw = 4;
+        o += nw * L.wstride;
+        const int64_t items = nblocks * nslices;
+        const int grid = (int)std::min<int64_t>((items + nw - 1) / nw, (int64_t)ctx->sm_count * 4);
+#define LDPC_RS_PK(VWV)                                                                                      \
+    {                                                                                                        \
+        auto kfn = rs_decode_packets_kernel<VWV>;                                                            \
+        LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(kfn)));                               \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * nw), (size_t)o, ctx->stream, a, L, nslices);          \
+    }
+        if (vw == 4) LDPC_RS_PK(4) else if (vw == 2) LDPC_RS_PK(2) else LDPC_RS_PK(1)
+#undef LDPC_RS_PK
+        LDPC_HIP_TRY(ctx, hipGetLastError());
+        return LDPC_AMD_OK;
+    }
+    if (S == 1 && R <= 32 && rs.k <= 256 && !rs_generic) {
         // one wavefront per block, system in registers
         RsFastLds L{};
         int o = 0;

@@ -192,11 +192,11 @@ def test_host_buffer_pipeline_matches_single_shot(ctx, code_a):
     era[60:70] = synth.erasures_uniform(603, 0, 10, n, 0.21)
     sym = cw.copy()
     sym[era.astype(bool)] = 0x77
-    os.environ["LDPC_AMD_HOST_PIPELINE"] = "0"
+    ctx.configure("LDPC_AMD_HOST_PIPELINE", 0)
     try:
         ref = ctx.decode(h, sym, era)
     finally:
-        os.environ.pop("LDPC_AMD_HOST_PIPELINE")
+        ctx.configure("LDPC_AMD_HOST_PIPELINE", None)
     got = ctx.decode(h, sym, era)
     for a, b in zip(got, ref):
         assert np.array_equal(a, b)

@@ -224,21 +224,21 @@ def test_full_4096_frame_packet_batches(bgpu, oracle, code_a, cfg):
         assert F == 4096 and int(st.max()) == 0
     else:
         assert F < 4096 and float((res > 0).float().mean()) >= 0.10 and int((st == 2).sum()) > 0   # ML runs, some systems are rank deficient
-        os.environ["LDPC_AMD_ML_SOLVE"] = "0"
+        g.ctx.configure("LDPC_AMD_ML_SOLVE", 0)
         try:
             out2, sw2, res2, st2 = g.ctx.decode(h, sym, era)
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("LDPC_AMD_ML_SOLVE", None)
+            g.ctx.configure("LDPC_AMD_ML_SOLVE", None)
         assert torch.equal(out2, out) and torch.equal(st2, st) and torch.equal(sw2, sw)
         # a small schedule arena: the first frames emit their solve schedules, the rest are solved inside the ML kernel --
         # both kinds in one batch, same bytes
-        os.environ["LDPC_AMD_ML_ARENA_WORDS"] = str(1 << 21)
+        g.ctx.configure("LDPC_AMD_ML_ARENA_WORDS", 1 << 21)
         try:
             out3, sw3, res3, st3 = g.ctx.decode(h, sym, era)
             torch.cuda.synchronize()
         finally:
-            os.environ.pop("LDPC_AMD_ML_ARENA_WORDS", None)
+            g.ctx.configure("LDPC_AMD_ML_ARENA_WORDS", None)
         assert torch.equal(out3, out) and torch.equal(st3, st)
         del out2, out3
     for lane in (0, 777):

@@ -1,5 +1,5 @@
-"""Every environment knob of DESIGN.md's appendix, at every non-default value: the library reads the knobs at each call, so
-one process can walk them.  A knob changes HOW a batch is decoded (kernel formulation, tiers, piece sizes, thread counts,
+"""Every knob of DESIGN.md's appendix, at every non-default value, set through ldpc_amd_configure (the LDPC_AMD_* environment
+variables only give the initial values, read once by ldpc_amd_init: checked below with a second context).  A knob changes HOW a batch is decoded (kernel formulation, tiers, piece sizes, thread counts,
 fall-backs) -- never a byte of the result: outputs, sweep counts, residual counts and status words must equal the default
 run's, which in turn is checked against the oracle.  The batch mixes frames message passing completes, frames that need the
 ML stage and rank-deficient ones, at S = 1 and as packets."""
@@ -20,7 +20,7 @@ KNOBS = [
     ("LDPC_AMD_SCATTER_R2", ["2", "3"]),
     ("LDPC_AMD_SCATTER_NT", ["0"]),
     ("LDPC_AMD_SCATTER_XCD", ["0"]),
-    ("LDPC_AMD_SCATTER_DYN", ["0", "2", "3"]),
+    ("LDPC_AMD_SCATTER_DYN", ["0", "2", "3", "4"]),
     ("LDPC_AMD_ENC_B", ["256"]),
     ("LDPC_AMD_ENC_LIST", ["1"]),
     ("LDPC_AMD_PEEL_GT", ["0", "1"]),
@@ -29,6 +29,9 @@ KNOBS = [
     ("LDPC_AMD_ML_SOLVE_B", ["64", "32", "16"]),
     ("LDPC_AMD_ML_ARENA_WORDS", ["20000"]),
     ("LDPC_AMD_ML_THREADS", ["256", "512", "768"]),
+    ("LDPC_AMD_ML_PACK", ["1", "3", "4"]),
+    ("LDPC_AMD_ML_RHS", ["0"]),
+    ("LDPC_AMD_RS", ["generic"]),
 ]
 
 
@@ -53,6 +56,8 @@ def test_every_knob_value_gives_the_default_bytes(ctx, oracle, code_a, S):
     F = 48
     src, era = _batch(code_a, S, F, 900 + S)
     saved = {k: os.environ.pop(k) for k, _ in KNOBS if k in os.environ}
+    for k, _ in KNOBS:
+        ctx.configure(k, None)
     try:
         cw0 = ctx.encode(h, src)
         sym = cw0.copy()
@@ -70,7 +75,7 @@ def test_every_knob_value_gives_the_default_bytes(ctx, oracle, code_a, S):
                 assert np.array_equal(out0[f], o) and sw0[f] == it and res0[f] == info[0]
         for knob, values in KNOBS:
             for v in values:
-                os.environ[knob] = v
+                ctx.configure(knob, v)
                 try:
                     cw = ctx.encode(h, src)
                     assert np.array_equal(cw, cw0), (knob, v, "encode")
@@ -78,6 +83,35 @@ def test_every_knob_value_gives_the_default_bytes(ctx, oracle, code_a, S):
                     assert np.array_equal(sw, sw0) and np.array_equal(res, res0) and np.array_equal(st, st0), (knob, v)
                     assert np.array_equal(out, out0), (knob, v)
                 finally:
-                    del os.environ[knob]
+                    ctx.configure(knob, None)
     finally:
         os.environ.update(saved)
+
+
+def test_environment_is_read_once_at_init_and_configure_rejects_nonsense(oracle, code_a):
+    """LDPC_AMD_* variables are the INITIAL knob values of a context (read inside ldpc_amd_init, nowhere else): a context
+    created under LDPC_AMD_APPLY=gather launches the gather kernel, changing the variable afterwards changes nothing, and an
+    existing context is not affected by the environment at all.  Unknown keys and out-of-range values are refused."""
+    h_src = synth.source(5, 0, 4, code_a.k, 64)
+    era = synth.erasures_uniform(6, 0, 4, code_a.n, 0.10)
+    os.environ["LDPC_AMD_APPLY"] = "gather"
+    try:
+        with api.Context(0) as c2:
+            os.environ["LDPC_AMD_APPLY"] = "scatter"      # too late for c2
+            h = c2.load_builtin_code(1, codes.DEFAULT_COEF_SEED[1])
+            cw = c2.encode(h, h_src)
+            sym = cw.copy()
+            sym[era.astype(bool)] = 0
+            out = c2.decode(h, sym, era)[0]
+            assert np.array_equal(out, cw)
+            assert c2.last_plan()["packet_bytes_per_workgroup"] == 0          # gather form: no packet (scatter) kernel plan
+            assert c2.profile_kernel_names()["apply"] == "ldpc_apply_kernel"
+            c2.configure("APPLY", "scatter")                                   # ... the configure call is how it changes
+            assert np.array_equal(c2.decode(h, sym, era)[0], cw)
+            assert c2.last_plan()["packet_bytes_per_workgroup"] == 64
+            for key, val in (("NO_SUCH_KNOB", "1"), ("SCATTER_B", "100"), ("ML_THREADS", "1000"), ("APPLY", "sideways")):
+                with pytest.raises(api.LdpcAmdError):
+                    c2.configure(key, val)
+            assert np.array_equal(c2.decode(h, sym, era)[0], cw)              # a refused value leaves the knob as it was
+    finally:
+        os.environ.pop("LDPC_AMD_APPLY", None)

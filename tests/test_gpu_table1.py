@@ -102,10 +102,7 @@ def test_streamed_run_equals_one_chunk(ctx):
     nframes = 1000
     want = None
     for chunk in ("", "64", "333"):
-        if chunk:
-            os.environ["LDPC_AMD_FPGA_CHUNK"] = chunk
-        else:
-            os.environ.pop("LDPC_AMD_FPGA_CHUNK", None)
+        ctx.configure("LDPC_AMD_FPGA_CHUNK", chunk or None)
         try:
             ctx.data_in(2040, 5, 12, 1, nframes)
             ctx.ldpc_erasure_decoder(50, 1)
@@ -116,7 +113,7 @@ def test_streamed_run_equals_one_chunk(ctx):
             left, its = ctx.fpga_frame_stats(nframes)
             got += (ctx.data_out(1, nframes), left.tolist(), its.tolist())
         finally:
-            os.environ.pop("LDPC_AMD_FPGA_CHUNK", None)
+            ctx.configure("LDPC_AMD_FPGA_CHUNK", None)
         if want is None:
             want = got
         assert got == want

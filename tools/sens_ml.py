@@ -24,7 +24,7 @@ out = torch.empty_like(sym)
 res = {}
 for rnd in range(5):
     for dbg in (0, 1, 2, 4, 8, 64, 128, 256, 16, 32, 4096, 8192):
-        os.environ["LDPC_AMD_ML_DBG"] = str(dbg)
+        g.ctx.configure("LDPC_AMD_ML_DBG", dbg)
         g.ctx.get_profile(); g.ctx.set_profiling(True)
         g.ctx.decode(h, sym, era, out=out)
         g.ctx.set_profiling(False)
@@ -40,7 +40,7 @@ out = torch.empty_like(sym)
 res = {}
 for rnd in range(4):
     for dbg in (0, 512, 1024, 2048):
-        os.environ["LDPC_AMD_ML_DBG"] = str(dbg)
+        g.ctx.configure("LDPC_AMD_ML_DBG", dbg)
         g.ctx.get_profile(); g.ctx.set_profiling(True)
         g.ctx.decode(h, sym, era, out=out)
         g.ctx.set_profiling(False)

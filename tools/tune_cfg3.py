@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A/B timing of the whole decode on the BASELINE cfg 3 batch (Gilbert-Elliott erasures, bench.py's generator) in ONE
-process, interleaved rounds.  Variants are the library's environment knobs (read at every call).  Every variant's output
+process, interleaved rounds.  Variants are the library's environment knobs (set per context with ldpc_amd_configure).  Every variant's output
 must equal the first one's bit for bit (rank-deficient frames included) and the codeword on every solved frame.
 Prints the median device time of every kernel kind (HIP events inside the library)."""
 import argparse
@@ -43,7 +43,7 @@ def main():
         for rnd in range(args.rounds + 1):
             for name, env in variants.items():
                 for kk, vv in env.items():
-                    os.environ[kk] = vv
+                    ctx.configure(kk, vv)
                 try:
                     out.fill_(0xEE)
                     ctx.get_profile()
@@ -53,7 +53,7 @@ def main():
                     prof = ctx.get_profile()
                 finally:
                     for kk in env:
-                        os.environ.pop(kk, None)
+                        ctx.configure(kk, None)
                 if rnd == 0 and not name.startswith("diag"):
                     ok = st <= 1
                     assert torch.equal(out[ok], cw[ok]), name

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of the hybrid ML stage on the BASELINE cfg 3 batch (Gilbert-Elliott erasures) in ONE process.
 
-Variants are the library's environment knobs (read at every call): LDPC_AMD_ML_THREADS=256|512|1024.
+Variants are the library's environment knobs (set per context with ldpc_amd_configure): LDPC_AMD_ML_THREADS=256|512|1024.
 Every variant's output must equal the first one's bit for bit (rank-deficient frames included) and the codeword on
 every solved frame.  Prints the median device time of the ML kernel (HIP events inside the library).
 """
@@ -53,7 +53,7 @@ def main():
         ctx.set_profiling(True)
         for rnd in range(args.rounds + 1):
             for name, env in variants.items():
-                os.environ.update(env)
+                ctx.configure_many(env)
                 out.zero_()
                 ctx.decode(h, sym, era, out=out, residual=rs, status=st)
                 prof = ctx.get_profile()

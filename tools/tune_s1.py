@@ -31,7 +31,7 @@ for code_ind, F in ((1, 4096), (1, 65536), (3, 65536)):
     plans = {}
     for rnd in range(6):
         for name, env in variants.items():
-            os.environ.update(env)
+            ctx.configure_many(env)
             try:
                 ctx.get_profile()
                 ctx.set_profiling(True)
@@ -41,7 +41,7 @@ for code_ind, F in ((1, 4096), (1, 65536), (3, 65536)):
                 plans[name] = ctx.last_plan()
             finally:
                 for kk in env:
-                    os.environ.pop(kk, None)
+                    ctx.configure(kk, None)
             assert torch.equal(out, cw), name
             if rnd:
                 times[name].append(t)

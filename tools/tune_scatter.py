@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of the packet decode kernels in ONE process, interleaved rounds (guide rule 24).
 
-Variants are selected through the library's environment knobs, which are read at every call:
+Variants are selected through the library's environment knobs, set per context with ldpc_amd_configure:
     LDPC_AMD_APPLY=gather|scatter   LDPC_AMD_SCATTER_R=2|4|8   LDPC_AMD_SCATTER_NT=0|1   LDPC_AMD_SCATTER_THREADS=...
 Prints median / min device time (HIP events inside the library) of the peel and apply kernels per variant.
 """
@@ -60,6 +60,8 @@ def main():
         "dyn0": {"LDPC_AMD_SCATTER_DYN": "0"},
         "dyn1": {"LDPC_AMD_SCATTER_DYN": "1"},
         "dyn2 list": {"LDPC_AMD_SCATTER_DYN": "2"},
+        "dyn3 sorted list": {"LDPC_AMD_SCATTER_DYN": "3"},
+        "dyn4 windowed sorted list": {"LDPC_AMD_SCATTER_DYN": "4"},
     }
     if args.variants:
         variants = {k: v for k, v in variants.items() if any(x in k for x in args.variants.split(","))}
@@ -69,8 +71,8 @@ def main():
     for rnd in range(args.rounds + 1):
         for name, env in variants.items():
             for kk in knobs:
-                os.environ.pop(kk, None)
-            os.environ.update(env)
+                ctx.configure(kk, None)
+            ctx.configure_many(env)
             ctx.decode(h, sym, era, out=out, sweeps=sw, residual=res, status=st)
             prof = ctx.get_profile()
             if rnd == 0:
