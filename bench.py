@@ -328,6 +328,7 @@ class Gpu:
         st = torch.empty(F, dtype=torch.int32, device=self.dev)
         for _ in range(warmup):
             ctx.decode(h, sym, era, out=out, sweeps=sw, residual=res, status=st)
+            ctx.synchronize()   # (untimed) the library sizes its ML schedule arena from the demand of the calls already finished
         ctx.get_profile()
         ctx.set_profiling(True)
         self.barrier()

@@ -99,6 +99,7 @@ static const KnobDesc kKnobs[] = {
     LDPC_KNOB_INT("ENC_LIST", enc_list, x == 0 || x == 1),
     {"RS", [](Knobs &k, const char *v) { if (!strcmp(v, "generic")) k.rs_generic = 1; else if (!strcmp(v, "fast")) k.rs_generic = 0; else return false; return true; },
      [](Knobs &k) { k.rs_generic = 0; }},
+    LDPC_KNOB_INT("RS_VW", rs_vw, x == 0 || x == 1 || x == 2 || x == 4),
     LDPC_KNOB_INT("HOST_PIPELINE", host_pipeline, x == 0 || x == 1),
     LDPC_KNOB_INT("FPGA_CHUNK", fpga_chunk, x >= 1),
 };
@@ -614,6 +615,7 @@ void ldpc_amd_cleanup(ldpc_amd_ctx *ctx)
     if (ctx->aux_out) (void)hipStreamDestroy(ctx->aux_out);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
+    if (ctx->ml_head_host) (void)hipHostFree(ctx->ml_head_host);
     delete ctx;
 }
 

@@ -84,7 +84,7 @@ struct Knobs {
     int scatter_xcd = 1;         // SCATTER_XCD: slices of a frame placed on one XCD
     int scatter_dyn = 1;         // SCATTER_DYN: 1 LDS counter, 0 fixed stride, 2 compacted list, 3 sorted list, 4 list sorted inside 64-row windows
     int scatter_r = 2;           // SCATTER_R: row pieces in flight per lane group, tier 1 (1, 2, 4)
-    int scatter_r2 = 4;          // SCATTER_R2: ... tier 2 (2, 3, 4)
+    int scatter_r2 = 3;          // SCATTER_R2: ... tier 2 (2, 3, 4)
     int peel_wpb = 0;            // PEEL_WPB: frames per peel workgroup (0 = auto)
     int peel_gt = -1;            // PEEL_GT: S = 1 kernel reads the code tables from global memory (-1 = auto)
     int ml_solve = 1;            // ML_SOLVE: 1 solve schedules + solve kernel, 0 solve inside the ML kernel, 2 emit only (diagnostic)
@@ -97,6 +97,7 @@ struct Knobs {
     int enc_b = 128;             // ENC_B: encoder piece size (128: two workgroups per CU; 256: the decoder's plan)
     int enc_list = 0;            // ENC_LIST: encoder streams the source rows in the order of their column degree
     int rs_generic = 0;          // RS=generic: RS decode always through the generic LDS kernel
+    int rs_vw = 0;               // RS_VW: dwords per lane of the packet RS kernel (0 = auto = 1; 2 and 4 where S allows)
     int host_pipeline = 1;       // HOST_PIPELINE: chunked upload / compute / download pipeline for large host buffers
     long fpga_chunk = 65536;     // FPGA_CHUNK: frames per chunk of the streamed FPGA-harness run
 };
@@ -130,6 +131,8 @@ struct ldpc_amd_ctx {
     ldpc_amd::Scratch mllist;   // [1 + nframes] int32: count, frame ids
     ldpc_amd::Scratch biglist;  // [1 + nframes] int32: frames with many steps (scatter tier 2)
     ldpc_amd::Scratch stage_in, stage_er, stage_out, stage_i32;  // host-pointer staging
+    unsigned long long *ml_head_host = nullptr;   // pinned: arena words the last packet-mode ML stage asked for
+    size_t ml_arena_words = 0;  // current size of the solve-schedule arena (64-bit words), grown on demand
     void *pin = nullptr;        // pinned host bounce block of the small-call path
     size_t pin_cap = 0;
     ldpc_amd::Scratch rsws;

@@ -962,7 +962,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
             uint32_t gm = (uint32_t)(__ballot(ew[q] != 0xFFFFFFFFu) >> gbase) & (uint32_t)((1ull << LPR) - 1ull);
             while (__any(gm != 0)) {
                 const bool go = gm != 0;
-                const int u = __builtin_ctz(gm);   // (gm == 0: any value -- such lanes read some lane and drop what they get)
+                const int u = gm ? __builtin_ctz(gm) : 0;   // (gm == 0: lane 0 of the group -- such lanes drop what they read; no poison from cttz(0))
                 gm &= gm - 1u;
                 const uint32_t ed = (uint32_t)__builtin_amdgcn_ds_bpermute((gbase + u) << 2, (int)ew[q]);
                 if (go) {
@@ -1540,8 +1540,9 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
         sa.tcap = sa.code.m; sa.nslots = sa.code.m; sa.big_list = big_list;
         scatter_set_lds(sa, p, sa.code.m);
         const dim3 g2((unsigned)std::min<int64_t>(sa.nframes * sa.nslices, ctx->sm_count));
-        // tier 2 runs one workgroup per CU (4 waves per SIMD, 128 VGPRs each): four row pieces in flight per lane group
-        // instead of two make up for part of the missing occupancy (cfg 3: 4.42 -> 4.19 ms); LDPC_AMD_SCATTER_R2=2 restores two
+        // tier 2 runs one workgroup per CU (4 waves per SIMD, 128 VGPRs each): more row pieces in flight per lane group make up
+        // for part of the missing occupancy.  Round 2: two / three / four pieces 4.50 / 4.28 / 4.24 ms on cfg 3 (four shipped, 160 B
+        // of spills per lane); round 3, with six vector instructions fewer per edge turn: 4.01 / 3.95 / 4.08 -- three ship (no spills)
         const int r2 = LPR == 16 ? kn.scatter_r2 : 0;
 #define LDPC_SCATTER_T2_R(RV, NTV, IPV)                                                                      \
     {                                                                                                        \
@@ -1773,8 +1774,18 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             if (cd.m * solve_b + tail_sv > kLdsMax || cd.n > 65535) ma.use_solve = 0;
         }
         if (ma.use_solve) {
-            size_t words = std::min<size_t>(std::max<size_t>((size_t)nf * 8192, (size_t)1 << 21), (size_t)1 << 27);   // 64 KB per frame; 16 MB ... 1 GB
+            // The arena follows DEMAND, not the batch size: 16 MB to start with (2 M words); the words the previous call asked for
+            // come back through a pinned host word (copied behind every call, never waited for), and when they exceeded three quarters of
+            // the arena it grows to twice that demand, at most 1 GB.  A call that overflows is still correct -- the frames
+            // that do not fit are solved inside the ML kernel -- so a steady workload is at full speed from its second or third
+            // batch, and a batch message passing completes pins 16 MB instead of 64 KB per frame.
+            size_t words = std::max<size_t>(ctx->ml_arena_words, (size_t)1 << 21);
+            if (ctx->ml_head_host) {
+                const unsigned long long need = *ctx->ml_head_host;   // demand of an earlier call (whatever has landed)
+                if (need > words / 4 * 3) words = std::min<size_t>(std::max<size_t>(words, (size_t)need * 2), (size_t)1 << 27);
+            }
             if (kn.ml_arena_words >= 1024) words = (size_t)kn.ml_arena_words;   // test knob: a small arena makes some frames fall back
+            ctx->ml_arena_words = kn.ml_arena_words >= 1024 ? ctx->ml_arena_words : words;
             if ((rc = scratch_reserve(ctx, ctx->mlops, words * 8)) || (rc = scratch_reserve(ctx, ctx->mlrec, (size_t)nf * 32))) return rc;
             ma.ops = (unsigned long long *)ctx->mlops.p; ma.ops_cap = words;
             ma.ops_head = (unsigned long long *)(ma.work + 2);
@@ -1817,6 +1828,14 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             LDPC_HIP_TRY(ctx, hipGetLastError());
         }
         prof_end(ctx, LDPC_AMD_PROF_ML, ev);
+        if (ma.use_solve) {   // this call's arena demand -> pinned host word, read by a later call (no wait here)
+            if (!ctx->ml_head_host) {
+                if (hipHostMalloc((void **)&ctx->ml_head_host, 64, hipHostMallocDefault) != hipSuccess) ctx->ml_head_host = nullptr;
+                else *ctx->ml_head_host = 0;
+            }
+            if (ctx->ml_head_host)
+                LDPC_HIP_TRY(ctx, hipMemcpyAsync(ctx->ml_head_host, ma.ops_head, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        }
     }
     return LDPC_AMD_OK;
 }
@@ -1900,7 +1919,12 @@ int launch_rs_decode(ldpc_amd_ctx *ctx, const HostRs &rs, int S, int64_t nblocks
     LDPC_HIP_TRY(ctx, hipMemsetAsync(a.bad, 0, sizeof(int), ctx->stream));
     if (S >= 256 && (S % 256) == 0 && R <= 32 && rs.k <= 256 && !rs_generic) {
         // packets: one wavefront per (block, slice), M^-1 in registers, rows streamed once, accumulators in registers
-        const int vw = (S % 1024) == 0 ? 4 : ((S % 512) == 0 ? 2 : 1);
+        // dwords per lane: 1 (a wavefront per 256-byte slice of the block, 32 accumulator registers, four wavefronts per SIMD) is
+        // the fastest -- 21.5 ms per 60 k blocks of 1 KB packets against 22.2 (2 dwords) and 24.9 (4 dwords: 256 registers, two
+        // wavefronts per SIMD cannot keep the vector ALU issuing); RS_VW = 2 / 4 are A/B knobs
+        int vw = 1;
+        if (ctx->knobs.rs_vw == 4 && (S % 1024) == 0) vw = 4;
+        else if (ctx->knobs.rs_vw == 2 && (S % 512) == 0) vw = 2;
         const int nslices = S / (256 * vw);
         RsPkLds L{};
         int o = 0;

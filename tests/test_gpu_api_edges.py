@@ -132,7 +132,11 @@ def test_cpp_host_harness_passes():
     r = subprocess.run([exe, "-h", "-c", "1", "-p", "9", "-n", "2000", "-i", "50"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert "PASSED" in r.stdout and "FAILED" not in r.stdout
-    assert "frame error rate" in r.stdout and "frames/sec" in r.stdout and "bits/sec: " not in r.stdout
+    assert "frame error rate" in r.stdout and "frames/sec" in r.stdout
+    # the reference harness's throughput line (OpenCL/host/src/main.cpp:652-655) is kept for scripts that parse it -- annotated,
+    # because this run moves erasure patterns only
+    tl = [ln for ln in r.stdout.splitlines() if ln.startswith("The throughput in information bits/sec: ")]
+    assert len(tl) == 1 and "pattern-only equivalent" in tl[0] and float(tl[0].split("bits/sec: ")[1].split()[0]) > 0
     # the paper's N_T = 1e6 at PER 12/64 (Table I, tex:207: BLER 0.02, RS 7.3e-3) through the CLI: the run is streamed
     r = subprocess.run([exe, "-h", "-c", "1", "-p", "12", "-n", "1000000", "-i", "50"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr

@@ -17,7 +17,7 @@ KNOBS = [
     ("LDPC_AMD_SCATTER_TIERS", ["1"]),
     ("LDPC_AMD_SCATTER_B", ["128", "64"]),
     ("LDPC_AMD_SCATTER_R", ["1", "4"]),
-    ("LDPC_AMD_SCATTER_R2", ["2", "3"]),
+    ("LDPC_AMD_SCATTER_R2", ["2", "4"]),
     ("LDPC_AMD_SCATTER_NT", ["0"]),
     ("LDPC_AMD_SCATTER_XCD", ["0"]),
     ("LDPC_AMD_SCATTER_DYN", ["0", "2", "3", "4"]),

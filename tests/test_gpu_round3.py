@@ -50,6 +50,12 @@ def test_rs_decode_packets_hundreds_of_blocks(ctx, oracle, n, k, S, B):
     msg = ctx.rs_decode(rs, idx, val)
     assert np.array_equal(msg, src)
     assert ctx.rs_bad_blocks() == 0
+    for vw in (2, 4):                      # the wider-lane instantiations of the streaming kernel (A/B knob)
+        ctx.configure("RS_VW", vw)
+        try:
+            assert np.array_equal(ctx.rs_decode(rs, idx, val), src), vw
+        finally:
+            ctx.configure("RS_VW", None)
     # arbitrary received values (not a codeword of anything in particular)
     junk = rng.integers(0, 256, size=val.shape).astype(np.uint8)
     jmsg = ctx.rs_decode(rs, idx, junk)

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--note", default="")
+    ap.add_argument("--workload", default="cfg2", help="bench.py workload the passes ran (cfg2, cfg3, cfg4p): bench.py replays traffic per workload")
     ap.add_argument("--valu", help="directory of a --pmc VALUBusy pass -> <tag>_valubusy.json")
     ap.add_argument("--outdir", default=None, help="where the summaries go (default: profiles/)")
     ap.add_argument("--cmd", default="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline", help="the profiled command (for the note)")
@@ -56,7 +57,7 @@ def main():
     if a.stats:
         src = find(a.stats, "*kernel_stats.csv")
         rows = [r for r in csv.reader(open(src))]
-        keep = [rows[0]] + [r for r in rows[1:] if "ldpc_amd" in r[0]]
+        keep = [rows[0]] + [r for r in rows[1:] if "ldpc_amd" in r[0]]   # (every kernel of the library lives in namespace ldpc_amd, RS included)
         with open(os.path.join(out, f"{a.tag}_kernel_stats.csv"), "w", newline="") as f:
             csv.writer(f).writerows(keep)
         print("stats:", len(keep) - 1, "kernels")
@@ -67,7 +68,7 @@ def main():
                         "fetch_bytes = 2 * FETCH_SIZE * 1024 (gfx950: wide coalesced reads are tallied at half), "
                         "write_bytes = WRITE_SIZE * 1024. For kernels launched with different batch shapes in one run "
                         "(peel: S=1 and packet batches) the mean mixes them; the max is the largest launch. " + a.note,
-                "kernels": {}}
+                "workload": a.workload, "kernels": {}}
         for k in sorted(set(fe) | set(wr)):
             f_kb, f_n, f_max = fe.get(k, (0.0, 0, 0.0))
             w_kb, w_n, w_max = wr.get(k, (0.0, 0, 0.0))
