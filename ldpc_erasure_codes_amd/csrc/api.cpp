@@ -94,7 +94,6 @@ static const KnobDesc kKnobs[] = {
     LDPC_KNOB_INT("ML_ARENA_WORDS", ml_arena_words, x == 0 || x >= 1024),
     LDPC_KNOB_INT("ML_THREADS", ml_threads, x == 0 || (x >= 256 && x <= 1024 && (x % 64) == 0)),
     LDPC_KNOB_INT("ML_PACK", ml_pack, x >= 1 && x <= 4),
-    LDPC_KNOB_INT("ML_RHS", ml_rhs, x == 0 || x == 1),
     LDPC_KNOB_INT("ENC_B", enc_b, x == 128 || x == 256),
     LDPC_KNOB_INT("ENC_LIST", enc_list, x == 0 || x == 1),
     {"RS", [](Knobs &k, const char *v) { if (!strcmp(v, "generic")) k.rs_generic = 1; else if (!strcmp(v, "fast")) k.rs_generic = 0; else return false; return true; },

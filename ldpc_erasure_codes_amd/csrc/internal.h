@@ -93,7 +93,6 @@ struct Knobs {
     long long ml_arena_words = 0;   // ML_ARENA_WORDS: size of the schedule arena in 64-bit words (0 = auto)
     int ml_threads = 0;          // ML_THREADS: threads of the ML kernel's workgroup (0 = 1024 / ML_PACK)
     int ml_pack = 2;             // ML_PACK: ML-kernel workgroups per CU (1, 2, 3, 4): 1024 / P threads and 160 KB / P of LDS each
-    int ml_rhs = 1;              // ML_RHS: 1 the packet kernel builds the ML stage's right-hand sides while it streams (0: the solve kernel re-reads the known rows)
     int enc_b = 128;             // ENC_B: encoder piece size (128: two workgroups per CU; 256: the decoder's plan)
     int enc_list = 0;            // ENC_LIST: encoder streams the source rows in the order of their column degree
     int rs_generic = 0;          // RS=generic: RS decode always through the generic LDS kernel

@@ -30,7 +30,6 @@ KNOBS = [
     ("LDPC_AMD_ML_ARENA_WORDS", ["20000"]),
     ("LDPC_AMD_ML_THREADS", ["256", "512", "768"]),
     ("LDPC_AMD_ML_PACK", ["1", "3", "4"]),
-    ("LDPC_AMD_ML_RHS", ["0"]),
     ("LDPC_AMD_RS", ["generic"]),
 ]
 
