@@ -15,6 +15,9 @@ sys.path.insert(0, ROOT)
 def main():
     import torch
     from ldpc_erasure_codes_amd import api, codes, synth
+    if len(sys.argv) > 1:          # another build of the library (A/B on one box)
+        api.LIB_PATH = os.path.abspath(sys.argv[1])
+    print("library:", api.LIB_PATH)
     ctx = api.Context(0)
     h = ctx.load_builtin_code(1, codes.DEFAULT_COEF_SEED[1])
     n, k, _ = ctx.code_info(h)
@@ -40,6 +43,23 @@ def main():
         t = min(ts)
         gb = 2.0 * F * n * S / 1e9
         print(f"S={S:5d}: {F} frames from/to host memory in {t * 1e3:8.1f} ms -> {F / t:10.0f} frames/s, {gb / t:6.2f} GB/s over PCIe (both directions summed)")
+        if S > 1:   # the encoder and the RS decoder through the same pipeline (round 3)
+            srch = np.ascontiguousarray(cw_h[:, :k, :])
+            ts = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                enc = ctx.encode(h, srch)
+                ts.append(time.perf_counter() - t0)
+            assert np.array_equal(enc, cw_h)
+            t = min(ts)
+            print(f"S={S:5d}: encode of {F} frames from/to host memory in {t * 1e3:8.1f} ms -> {F / t:10.0f} frames/s, {F * (n + k) * S / 1e9 / t:6.2f} GB/s over PCIe")
+            for pipe in ((0, 1) if hasattr(ctx._L, "ldpc_amd_configure") else ()):
+                ctx.configure("HOST_PIPELINE", pipe)
+                t0 = time.perf_counter()
+                enc = ctx.encode(h, srch)
+                print(f"          encode, HOST_PIPELINE={pipe}: {(time.perf_counter() - t0) * 1e3:8.1f} ms")
+            if hasattr(ctx._L, "ldpc_amd_configure"):
+                ctx.configure("HOST_PIPELINE", None)
     ctx.close()
 
 
