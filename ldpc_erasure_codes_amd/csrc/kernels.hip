@@ -1935,14 +1935,16 @@ int launch_rs_decode(ldpc_amd_ctx *ctx, const HostRs &rs, int S, int64_t nblocks
         const int nw = 4;
         o += nw * L.wstride;
         const int64_t items = nblocks * nslices;
-        const int grid = (int)std::min<int64_t>((items + nw - 1) / nw, (int64_t)ctx->sm_count * 4);
-#define LDPC_RS_PK(VWV)                                                                                      \
+        const int grid = (int)std::min<int64_t>((items + nw - 1) / nw, (int64_t)ctx->sm_count * 96);
+#define LDPC_RS_PK(VWV, WPSV)                                                                                \
     {                                                                                                        \
-        auto kfn = rs_decode_packets_kernel<VWV>;                                                            \
+        auto kfn = rs_decode_packets_kernel<VWV, WPSV>;                                                      \
         LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(kfn)));                               \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(64 * nw), (size_t)o, ctx->stream, a, L, nslices);          \
     }
-        if (vw == 4) LDPC_RS_PK(4) else if (vw == 2) LDPC_RS_PK(2) else LDPC_RS_PK(1)
+        // (one dword per lane compiled for four wavefronts per SIMD: 19.9 ms; for six / eight -- 80 / 64 registers, the Gauss-Jordan
+        // part spills -- 31.0 / 26.6 ms)
+        if (vw == 4) LDPC_RS_PK(4, 2) else if (vw == 2) LDPC_RS_PK(2, 4) else LDPC_RS_PK(1, 4)
 #undef LDPC_RS_PK
         LDPC_HIP_TRY(ctx, hipGetLastError());
         return LDPC_AMD_OK;

@@ -214,3 +214,26 @@ def test_small_host_calls_take_the_packed_path(ctx, oracle, code_a):
         out2 = np.zeros_like(out)
         assert L.ldpc_amd_decode_batch(ctx._h, h, 1, F, sym.ctypes.data, era.ctypes.data, 10, 1, out2.ctypes.data, None, None, None, 0) == 0
         assert np.array_equal(out2, out)
+
+
+def test_rs_packets_fuzz_over_code_shapes(ctx, oracle):
+    """Seeded fuzz of the RS packet path over (n, k, S): every n - k <= 32 shape takes the streaming kernel (S a multiple of 256),
+    others the generic one; random numbers of missing symbols per block.  Every block against its source, sampled byte lanes
+    against the oracle (Matlab/My_RS_Decode_Optimize_With_GFTables.m restated)."""
+    rng = np.random.default_rng(20261004)
+    shapes = [(255, 223), (255, 239), (200, 180), (64, 32), (40, 36), (33, 1), (17, 16), (255, 224), (100, 60), (255, 128)]
+    for (n, k) in shapes:
+        rs = ctx.rs_create(n, k)
+        G = ctx.rs_generator(rs, n, k)
+        for S in (256, 768, 1280):
+            B = 24
+            src = rng.integers(0, 256, size=(B, k, S)).astype(np.uint8)
+            cw = ctx.rs_encode(rs, n, k, src)
+            idx = np.stack([np.sort(rng.permutation(n)[: n - int(rng.integers(0, n - k + 1))])[:k] for _ in range(B)]).astype(np.uint16)
+            val = np.stack([cw[b, idx[b].astype(np.int64)] for b in range(B)])
+            msg = ctx.rs_decode(rs, idx, val)
+            assert np.array_equal(msg, src), (n, k, S)
+            for b in (0, B // 2, B - 1):
+                lane = int(rng.integers(0, S))
+                o, rc = oracle.rs_decode(G, idx[b], np.ascontiguousarray(val[b, :, lane]))
+                assert rc == 0 and np.array_equal(msg[b, :, lane], o), (n, k, S, b, lane)
