@@ -219,7 +219,7 @@ struct PeelArgs {
     uint32_t *sched_steps;  // [nframes][m]
     uint16_t *sched_lvlend; // [nframes][m+1]
     uint8_t *sched_invc;    // [nframes][m]  inverse of the coefficient step i divides by (packet kernel)
-    int32_t *big_list;      // [0] = count, [1..] frames with more than tcap steps (scatter tier 2), or nullptr
+    int32_t *big_list;      // [0] = count, [1] = tier 2's work counter, [2..] frames with more than tcap steps (scatter tier 2), or nullptr
     int tcap;
     // ML hand-off
     int32_t *ml_list;       // [0] = count, [1..kMlClasses] = counts of the size classes, [kMlHdr + slot] = frame id,
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(1024) void ldpc_peel_kernel(PeelArgs a)
         if (lane == 0) {
             a.sched_hdr[2 * f] = (uint32_t)nsteps;
             a.sched_hdr[2 * f + 1] = (uint32_t)maxlvl;
-            if (a.big_list && nsteps > a.tcap) a.big_list[1 + atomicAdd(&a.big_list[0], 1)] = (int32_t)f;
+            if (a.big_list && nsteps > a.tcap) a.big_list[2 + atomicAdd(&a.big_list[0], 1)] = (int32_t)f;
         }
         uint32_t *gs = a.sched_steps + f * m;
         uint8_t *gi = a.sched_invc + f * m;
@@ -602,7 +602,7 @@ struct ScatterArgs {
     int dyn_rows;             // streaming phase: row batches handed out through an LDS counter
     int tcap;                 // tier 1 handles frames with at most tcap steps (its LDS holds tcap accumulators)
     int nslots;               // accumulator slots in this launch's LDS (tcap in tier 1, m in tier 2 / encode)
-    const int32_t *big_list;  // tier 2: [0] = count, [1..] ids of the frames with more steps; nullptr in tier 1
+    int32_t *big_list;        // tier 2: [0] = count, [1] = work counter, [2..] ids of the frames with more steps; nullptr in tier 1
     int lds_acc, lds_tgt, lds_invc, lds_lvlend, lds_rowctr, lds_mt, lds_soc, lds_chk;
     int lds_soc_bytes;        // size of the row-kind / row-list region
     int enc_list;             // encode: stream the source rows in DevCode::enc_order
@@ -1199,10 +1199,17 @@ template <int LPR, int R, bool NT, bool INPLACE>
 __global__ __launch_bounds__(1024) void ldpc_scatter_big_kernel(ScatterArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int64_t items = (int64_t)a.big_list[0] * a.nslices;
-    for (int64_t it = blockIdx.x; it < items; it += gridDim.x) {
+    // work items (frame, slice) are handed out through a device counter, first come first served: their cost varies with the
+    // frame's steps and levels, and with ~50 items per workgroup a fixed stride leaves the slowest workgroup a few items behind
+    const int items = a.big_list[0] * a.nslices;
+    int *slot = reinterpret_cast<int *>(smem + a.lds_rowctr) + 2;   // (ints 0 / 1 of the region are re-initialised by every frame)
+    for (;;) {
         __syncthreads();
-        scatter_frame<LPR, R, NT, INPLACE>(a, smem, a.big_list[1 + it / a.nslices], (int)(it % a.nslices));
+        if (threadIdx.x == 0) *slot = atomicAdd(&a.big_list[1], 1);
+        __syncthreads();
+        const int it = *slot;
+        if (it >= items) break;
+        scatter_frame<LPR, R, NT, INPLACE>(a, smem, a.big_list[2 + it / a.nslices], (int)(it % a.nslices));
     }
 }
 
@@ -1503,7 +1510,7 @@ static void scatter_set_lds(ScatterArgs &sa, const ScatterPlan &p, int nacc)
 }
 
 template <int LPR, int R>
-static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterArgs sa, const int32_t *big_list)
+static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterArgs sa, int32_t *big_list)
 {
     constexpr int THREADS = (LPR >= 8) ? 1024 : (LPR >= 2 ? 512 : 256);
     const Knobs &kn = ctx->knobs;
@@ -1563,7 +1570,7 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
     return LDPC_AMD_OK;
 }
 
-static int launch_scatter(ldpc_amd_ctx *ctx, const ScatterPlan &p, const ScatterArgs &sa, const int32_t *big_list)
+static int launch_scatter(ldpc_amd_ctx *ctx, const ScatterPlan &p, const ScatterArgs &sa, int32_t *big_list)
 {
     const int rr = ctx->knobs.scatter_r;
     switch (p.lpr) {
@@ -1654,8 +1661,8 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     if (d.do_ml && (rc = scratch_reserve(ctx, ctx->mlstate, (size_t)nf * cd.n))) return rc;
     LDPC_HIP_TRY(ctx, hipMemsetAsync(ctx->mllist.p, 0, kMlHdr * sizeof(int32_t), ctx->stream));
     if (use_scatter && plan.two_tier) {
-        if ((rc = scratch_reserve(ctx, ctx->biglist, sizeof(int32_t) * (size_t)(nf + 1)))) return rc;
-        LDPC_HIP_TRY(ctx, hipMemsetAsync(ctx->biglist.p, 0, sizeof(int32_t), ctx->stream));
+        if ((rc = scratch_reserve(ctx, ctx->biglist, sizeof(int32_t) * (size_t)(nf + 2)))) return rc;
+        LDPC_HIP_TRY(ctx, hipMemsetAsync(ctx->biglist.p, 0, 2 * sizeof(int32_t), ctx->stream));   // [0] count, [1] tier 2's work counter
     }
 
     PeelArgs pa{};
@@ -1701,7 +1708,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             sa.sched_hdr = pa.sched_hdr; sa.sched_steps = pa.sched_steps; sa.sched_lvlend = pa.sched_lvlend;
             sa.sched_invc = pa.sched_invc;
             ev = prof_begin(ctx);
-            if ((rc = launch_scatter(ctx, plan, sa, (const int32_t *)ctx->biglist.p))) return rc;
+            if ((rc = launch_scatter(ctx, plan, sa, (int32_t *)ctx->biglist.p))) return rc;
             prof_end(ctx, LDPC_AMD_PROF_APPLY, ev);
         } else {
         ApplyArgs aa{};
