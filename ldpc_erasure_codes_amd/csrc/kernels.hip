@@ -1780,6 +1780,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             while (solve_b > 16 && cd.m * solve_b + tail_sv > 79 * 1024) solve_b >>= 1;
             if (cd.m * solve_b + tail_sv > kLdsMax || cd.n > 65535) ma.use_solve = 0;
         }
+        ma.solve_b = solve_b;
         if (ma.use_solve) {
             // The arena follows DEMAND, not the batch size: 16 MB to start with (2 M words); the words the previous call asked for
             // come back through a pinned host word (copied behind every call, never waited for), and when they exceeded three quarters of
@@ -1813,9 +1814,9 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             sv.code = cd; sv.S = d.S; sv.nslices = d.S / solve_b; sv.nframes = nf; sv.ml_list = ma.ml_list; sv.rec = ma.rec; sv.ops = ma.ops;
             sv.out = d.out; sv.work = ma.work + 4;
             sv.dbg = ma.dbg;
-            int o = cd.m * solve_b;
+            int o = 8192 + cd.m * solve_b;   // multiply tables first (kMlSlot0), then the slots
             sv.lds_tab = o; o += align_up(4 * (2 * cd.m + 6), 16);
-            sv.lds_mt = o; o += 8192;
+            sv.lds_mt = 0;
             sv.lds_misc = o; o += 16 + 4 * kMlClasses;
             const int per_cu = std::max(1, std::min(4, kLdsMax / o));
             const dim3 sg((unsigned)std::min<int64_t>(nf * sv.nslices, (int64_t)ctx->sm_count * per_cu));
