@@ -237,3 +237,17 @@ def test_rs_packets_fuzz_over_code_shapes(ctx, oracle):
                 lane = int(rng.integers(0, S))
                 o, rc = oracle.rs_decode(G, idx[b], np.ascontiguousarray(val[b, :, lane]))
                 assert rc == 0 and np.array_equal(msg[b, :, lane], o), (n, k, S, b, lane)
+
+
+def test_repeated_decodes_of_the_bench_batches_are_identical():
+    """The accumulation ORDER of a decode is not fixed (LDS atomics, work items handed out first come first served, two ML
+    systems per CU, the larger matrices in the L2-backed scratch); its RESULT is: the 4096-frame cfg 3 batch (hybrid ML,
+    rank-deficient frames included) and the cfg 2 batch, decoded repeatedly, give the same bytes and status words every time
+    (tools/stress_repeat.py; the first run is also held against the codewords)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_repeat.py"), "5"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("identical") == 5 and "NOT identical" not in r.stdout
