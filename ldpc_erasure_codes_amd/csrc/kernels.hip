@@ -618,17 +618,9 @@ __device__ __forceinline__ MulTab lds_multab(const uint32_t *mt, uint32_t c)
     return t;
 }
 
-// acc(16 bytes at p) ^= v, as two ds_xor_b64.  Lanes 8..15 of every 16-lane group issue their halves in the
-// opposite order, so that one instruction touches all 32 LDS banks exactly once per 16 lanes.
-__device__ __forceinline__ void lds_xor16(unsigned char *p, const U4 &v, int h)
-{
-    const unsigned long long lo = (unsigned long long)v.x | ((unsigned long long)v.y << 32);
-    const unsigned long long hi = (unsigned long long)v.z | ((unsigned long long)v.w << 32);
-    unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
-    __hip_atomic_fetch_xor(q + h, h ? hi : lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    __hip_atomic_fetch_xor(q + (1 - h), h ? lo : hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
+// acc(16 bytes) ^= v goes to LDS as two ds_xor_b64.  Interleaved layout (a lane's 16 bytes contiguous): lanes 8..15 of every
+// 16-lane group issue their halves in the opposite order, so that one instruction touches all 32 LDS banks exactly once per
+// 16 lanes (lds_xor16_at below).
 // Split-half layout of a 16-bytes-per-lane accumulator slice (G lanes x 16 B): the G low halves first (8 B per lane), then
 // the G high halves.  One ds_xor_b64 then covers 8 G contiguous bytes -- every bank once per 16 lanes -- without the per-lane
 // choice of which half goes first (four v_cndmask_b32 per accumulate in the interleaved layout).  a_lo / a_hi: LDS byte addresses.
