@@ -318,7 +318,7 @@ class Gpu:
         sym[era.bool()] = 0x5A  # the payload of an erased symbol is garbage, never the true value
         return cw, sym, era, keep
 
-    def time_decode(self, h, sym, era, steps, warmup, after_steps=None):
+    def time_decode(self, h, sym, era, steps, warmup, after_steps=None, detail=False):
         """W untimed + K timed decode steps bracketed by barrier + synchronize; per-kernel HIP-event times from the library."""
         torch, ctx = self.torch, self.ctx
         F = sym.shape[0]
@@ -340,9 +340,17 @@ class Gpu:
         dt = time.perf_counter() - t0
         ctx.set_profiling(False)
         prof = ctx.get_profile()
+        if detail:   # break-down of the two-kernel kinds (tier 2 alone, solve kernel alone): two more steps OUTSIDE the timed region
+            ctx.set_profiling(2)
+            for _ in range(2):
+                ctx.decode(h, sym, era, out=out, sweeps=sw, residual=res, status=st)
+            ctx.set_profiling(False)
+            p2 = ctx.get_profile()
+            for kk in ("apply_tier2", "ml_solve"):
+                prof[kk] = p2[kk]
         names = ctx.profile_kernel_names()
         return dict(dt=dt, out=out, sw=sw, res=res, st=st, extra=extra, names=names,
-                    kernel_ms={kk: (v[0] / max(v[1], 1)) for kk, v in prof.items()})
+                    kernel_ms={kk: (v[0] / max(v[1], 1)) for kk, v in prof.items() if v[1] > 0})
 
 
 def summarize(g, r, cw, n, k, S, steps, frames_all_ranks):
@@ -420,6 +428,7 @@ def run_cfg2(g, args):
         s["sample"] = pick_samples(r, sym, era, False)
         kind = "apply" if S > 1 else "peel"
         kavg = r["kernel_ms"][kind]  # ms per launch of the dominant kernel, HIP events on its own stream
+
         ab = alg_bytes_per_frame(n, S) * F
         ach = ab / (kavg * 1e-3) / 1e9 if kavg > 0 else 0.0
         copy_gbps = None
@@ -497,7 +506,7 @@ def run_cfg3(g, args, S):
     h, n, k = g.code(1)
     cw, sym, era, keep = g.make_batch("cfg3", 1, S, frame0=0, nframes=WORKLOADS["cfg3"]["frames"])
     steps = max(3, min(args.steps, 10))
-    r = g.time_decode(h, sym, era, steps, min(args.warmup, 2))
+    r = g.time_decode(h, sym, era, steps, min(args.warmup, 2), detail=True)
     s = summarize(g, r, cw, n, k, S, steps, cw.shape[0])
     s["workload"] = (f"S={S} bytes/symbol, BASELINE cfg3: (2040,1530) hybrid MP+ML, Gilbert-Elliott alpha={GE_PARAMS[0]} beta={GE_PARAMS[1]} "
                      f"bias={GE_PARAMS[2]:g} (chain carried across frames), {WORKLOADS['cfg3']['frames']} frames drawn, "
@@ -577,7 +586,7 @@ def run_cfg4_packets(g, args, S=1024):
                      f"tools/hgen.cpp -- the reference names the code but does not ship it], uniform 10 %, {F} frames "
                      f"(= {2 * F * n * S / 1e9:.1f} GB in + out; 65536 frames x 1 KB packets would be 548 GB)")
     s["verified"] = s["verified"] and int(r["st"].max()) == 0
-    kavg = r["kernel_ms"]["apply"]
+    kavg = r["kernel_ms"]["apply"]   # both tiers (tier 2 takes the handful of frames with more than tcap steps)
     ab = alg_bytes_per_frame(n, S) * F
     ach = ab / (kavg * 1e-3) / 1e9 if kavg > 0 else 0.0
     traffic, tsrc = pmc_traffic(r["names"]["apply"], "cfg4p")

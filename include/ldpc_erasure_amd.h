@@ -203,9 +203,13 @@ int ldpc_amd_data_out(ldpc_amd_ctx *ctx, ldpc_amd_symbol_type *data_out, int cod
  * the context's stream; ldpc_amd_get_profile synchronises, returns the summed device time (ms) and launch count per
  * kernel kind since the last call, and resets the counters. */
 #define LDPC_AMD_PROF_PEEL 0   /* ldpc_peel_kernel  (schedule; + apply when S = 1) */
-#define LDPC_AMD_PROF_APPLY 1  /* ldpc_apply_kernel (packet rows: the HBM-bound kernel) */
-#define LDPC_AMD_PROF_ML 2     /* ldpc_ml_kernel    (Gaussian elimination on residual frames) */
-#define LDPC_AMD_PROF_KINDS 3
+#define LDPC_AMD_PROF_APPLY 1  /* packet kernel(s): ldpc_scatter_kernel (tier 1) + ldpc_scatter_big_kernel (tier 2), or ldpc_apply_kernel */
+#define LDPC_AMD_PROF_ML 2     /* ldpc_ml_kernel + ldpc_ml_solve_kernel (Gaussian elimination on residual frames) */
+#define LDPC_AMD_PROF_APPLY_TIER2 3 /* the tier-2 launch of the packet kernel alone (already inside LDPC_AMD_PROF_APPLY) */
+#define LDPC_AMD_PROF_ML_SOLVE 4    /* ldpc_ml_solve_kernel alone (already inside LDPC_AMD_PROF_ML) */
+#define LDPC_AMD_PROF_KINDS 5
+/* enable: 0 off; 1 one bracket per kind of a call (PEEL, APPLY, ML); 2 additionally the nested brackets APPLY_TIER2 and ML_SOLVE
+ * (two more event pairs per call: use it for break-downs, not inside a timed region that is quoted as throughput). */
 int ldpc_amd_set_profiling(ldpc_amd_ctx *ctx, int enable);
 int ldpc_amd_get_profile(ldpc_amd_ctx *ctx, double ms[LDPC_AMD_PROF_KINDS], int64_t launches[LDPC_AMD_PROF_KINDS]);
 /* Name (as rocprofv3 prints it, e.g. "ldpc_scatter_kernel<16, 2, true, 8, false>") of the kernel instantiation the LAST

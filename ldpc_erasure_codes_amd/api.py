@@ -26,6 +26,9 @@ OK = 0
 DEVICE_PTRS = 1
 INPLACE = 2
 ST_MP_DONE, ST_ML_SOLVED, ST_ML_RANKDEF, ST_ML_SKIPPED = 0, 1, 2, 3
+# LDPC_AMD_PROF_*: "apply" = both tiers of the packet kernel ("apply_tier2" is the tier-2 launch alone), "ml" = factorisation + solve
+# ("ml_solve" is the solve kernel alone)
+PROF_KINDS = ("peel", "apply", "ml", "apply_tier2", "ml_solve")
 
 # every symbol include/ldpc_erasure_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -208,18 +211,19 @@ class Context:
             self.configure(k, v)
 
     def set_profiling(self, enable):
-        self._check(self._L.ldpc_amd_set_profiling(self._h, int(bool(enable))), "set_profiling")
+        """False / 0: off; True / 1: one bracket per kind of a call; 2: + the nested tier-2 and solve-kernel brackets."""
+        self._check(self._L.ldpc_amd_set_profiling(self._h, int(enable)), "set_profiling")
 
     def get_profile(self):
-        """{'peel': (ms, launches), 'apply': ..., 'ml': ...} since the last call (synchronises)."""
-        ms = (C.c_double * 3)()
-        cnt = (C.c_int64 * 3)()
+        """{'peel': (ms, launches), 'apply': ..., 'ml': ..., 'apply_tier2': ..., 'ml_solve': ...} since the last call (synchronises)."""
+        ms = (C.c_double * len(PROF_KINDS))()
+        cnt = (C.c_int64 * len(PROF_KINDS))()
         self._check(self._L.ldpc_amd_get_profile(self._h, ms, cnt), "get_profile")
-        return {name: (ms[i], cnt[i]) for i, name in enumerate(("peel", "apply", "ml"))}
+        return {name: (ms[i], cnt[i]) for i, name in enumerate(PROF_KINDS)}
 
     def profile_kernel_names(self):
         """{'peel': name, 'apply': name, 'ml': name}: the kernel instantiation the last launch of each kind used."""
-        return {name: self._L.ldpc_amd_profile_kernel_name(self._h, i).decode() for i, name in enumerate(("peel", "apply", "ml"))}
+        return {name: self._L.ldpc_amd_profile_kernel_name(self._h, i).decode() for i, name in enumerate(PROF_KINDS)}
 
     def last_plan(self):
         info = (C.c_int * 8)()

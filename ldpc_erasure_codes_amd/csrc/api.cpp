@@ -179,9 +179,9 @@ static hipEvent_t prof_take(ldpc_amd_ctx *ctx)
     return e;
 }
 
-hipEvent_t prof_begin(ldpc_amd_ctx *ctx)
+hipEvent_t prof_begin(ldpc_amd_ctx *ctx, int level)
 {
-    if (!ctx->profiling) return nullptr;
+    if (ctx->profiling < level) return nullptr;
     hipEvent_t e = prof_take(ctx);
     if (e) (void)hipEventRecord(e, ctx->stream);
     return e;
@@ -1120,7 +1120,7 @@ int ldpc_amd_data_out(ldpc_amd_ctx *ctx, ldpc_amd_symbol_type *data_out, int cod
 int ldpc_amd_set_profiling(ldpc_amd_ctx *ctx, int enable)
 {
     if (!ctx) return LDPC_AMD_EINVAL;
-    ctx->profiling = enable != 0;
+    ctx->profiling = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
     return LDPC_AMD_OK;
 }
 

@@ -151,7 +151,7 @@ struct ldpc_amd_ctx {
     int sm_count = 256;
     ldpc_amd::Knobs knobs;
     // profiling (ldpc_amd_set_profiling): event pairs per kernel kind
-    bool profiling = false;
+    int profiling = 0;          // 0 off, 1 the three kinds of a call, 2 + the nested brackets (tier 2 alone, solve kernel alone)
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events[LDPC_AMD_PROF_KINDS];
     std::vector<hipEvent_t> prof_pool;
     std::string prof_names[LDPC_AMD_PROF_KINDS];   // template instantiation the last launch of each kind used
@@ -198,7 +198,7 @@ int launch_fpga_stats(ldpc_amd_ctx *ctx, const DevCode &code, int rs_n, int rs_k
 
 int scratch_reserve(ldpc_amd_ctx *ctx, Scratch &s, size_t bytes);
 // Brackets one kernel launch with events when profiling is on (no-ops otherwise).
-hipEvent_t prof_begin(ldpc_amd_ctx *ctx);
+hipEvent_t prof_begin(ldpc_amd_ctx *ctx, int level = 1);
 void prof_end(ldpc_amd_ctx *ctx, int kind, hipEvent_t start);
 int set_error(ldpc_amd_ctx *ctx, int code, const char *fmt, ...);
 

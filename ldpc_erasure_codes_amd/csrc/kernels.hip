@@ -1553,10 +1553,18 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
     if (r2 == 4) LDPC_SCATTER_T2_R((LPR == 16 ? 4 : R), NTV, IPV)                                            \
     else if (r2 == 3) LDPC_SCATTER_T2_R((LPR == 16 ? 3 : R), NTV, IPV)                                       \
     else LDPC_SCATTER_T2_R(R, NTV, IPV)
+        {
+            char nm[96];
+            snprintf(nm, sizeof(nm), "ldpc_scatter_big_kernel<%d, %d, %s, %s>", LPR, (LPR == 16 && (r2 == 3 || r2 == 4)) ? r2 : R, nt ? "true" : "false",
+                     ip ? "true" : "false");
+            ctx->prof_names[LDPC_AMD_PROF_APPLY_TIER2] = nm;
+        }
+        hipEvent_t ev2 = prof_begin(ctx, 2);
         if (ip) { if (nt) LDPC_SCATTER_T2(true, true) else LDPC_SCATTER_T2(false, true) }
         else { if (nt) LDPC_SCATTER_T2(true, false) else LDPC_SCATTER_T2(false, false) }
 #undef LDPC_SCATTER_T2_R
 #undef LDPC_SCATTER_T2
+        prof_end(ctx, LDPC_AMD_PROF_APPLY_TIER2, ev2);
         LDPC_HIP_TRY(ctx, hipGetLastError());
     }
     return LDPC_AMD_OK;
@@ -1818,6 +1826,12 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(sfn)));                               \
         hipLaunchKernelGGL(sfn, sg, dim3(512), (size_t)o, ctx->stream, sv);                                  \
     }
+            {
+                char nm[64];
+                snprintf(nm, sizeof(nm), "ldpc_ml_solve_kernel<%d>", solve_b / 16);
+                ctx->prof_names[LDPC_AMD_PROF_ML_SOLVE] = nm;
+            }
+            hipEvent_t evs = prof_begin(ctx, 2);
             switch (solve_b) {
                 case 128: LDPC_ML_SOLVE(8) break;
                 case 64: LDPC_ML_SOLVE(4) break;
@@ -1825,6 +1839,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
                 default: LDPC_ML_SOLVE(1) break;
             }
 #undef LDPC_ML_SOLVE
+            prof_end(ctx, LDPC_AMD_PROF_ML_SOLVE, evs);
             LDPC_HIP_TRY(ctx, hipGetLastError());
         }
         prof_end(ctx, LDPC_AMD_PROF_ML, ev);
