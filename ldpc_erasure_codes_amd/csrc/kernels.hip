@@ -1012,11 +1012,14 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
             }
         }
     };
+    // rows the streaming phase walks: all n for the decoder; the encoder's parity rows (j >= k) are all produced by the level
+    // phase, so its stream ends at k (a quarter of the (2040,1530) rows)
+    const int nstream = a.static_sched ? a.in_rows : n;
     auto fetch = [&](int j0, RowBatch &b) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int j = j0 + r * RPW + g;
-            const int kd = (j < n) ? (int)rk[j] : 0;
+            const int kd = (j < nstream) ? (int)rk[j] : 0;
             b.kind[r] = kd;
             b.v[r] = U4{0, 0, 0, 0};
 #pragma unroll
@@ -1072,7 +1075,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
             if (lane == 0) j0 = atomicAdd(rowctr, step);
             j0 = __builtin_amdgcn_readfirstlane(j0);
             fetch(j0, cur);
-            while (j0 < n) {
+            while (j0 < nstream) {
                 if (lane == 0) j1 = atomicAdd(rowctr, step);
                 j1 = __builtin_amdgcn_readfirstlane(j1);
                 fetch(j1, nxt);
@@ -1090,7 +1093,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
             const int stride = nw * step;
             int j0 = wave * step;
             fetch(j0, cur);
-            for (; j0 < n; j0 += stride) {
+            for (; j0 < nstream; j0 += stride) {
                 fetch(j0 + stride, nxt);
 #pragma unroll
                 for (int r = 0; r < R; r++) {
