@@ -15,7 +15,10 @@ line says so: ml_trigger_rate); the configs that exercise it are in the "configs
     cfg3  (2040,1530) hybrid MP+ML, Gilbert-Elliott erasures pushed until the ML stage triggers on >= 10 % of the frames
           (SURVEY.md 8d), S = 1024 and S = 1
     cfg4  (4080,3060) [synthesised matrix] vs 16 x RS(255,223) on the same erasure patterns, 65536 frames, S = 1
-    cfg5  mixed (4000,2000) + (2040,1530) stream, 1:1, 10 % -- at N = 1 one GPU's share (8192 frames) of the 8-GPU job
+          + cfg4_S1024: the same code and RS(255,223) in packet mode (S = 1024), the first 4096 frames of that stream
+          (alone: `--config 4 --S 1` / `--config 4 --S 1024`)
+    cfg5  mixed (4000,2000) + (2040,1530) stream, 1:1, 10 % -- at N = 1 the whole 65536-frame stream (the strong-scaling anchor),
+          one GPU's 1/8 share, and an S = 64 run whose final gather moves the decoded outputs
 
 each with frames/s, per-kernel ms (HIP events inside the library, on the launch stream), algorithmic bytes,
 the roofline fraction they give, ML-trigger / rank-deficient rates and a bounded CPU-baseline sample of the same inputs.
