@@ -94,6 +94,9 @@ static const KnobDesc kKnobs[] = {
     LDPC_KNOB_INT("ML_ARENA_WORDS", ml_arena_words, x == 0 || x >= 1024),
     LDPC_KNOB_INT("ML_THREADS", ml_threads, x == 0 || (x >= 256 && x <= 1024 && (x % 64) == 0)),
     LDPC_KNOB_INT("ML_PACK", ml_pack, x >= 1 && x <= 4),
+    LDPC_KNOB_INT("ML_PI", ml_pi, x >= 0 && x <= 2),
+    LDPC_KNOB_INT("ML_OVERLAP", ml_overlap, x >= 0 && x <= 1),
+    LDPC_KNOB_INT("ML_PI_LDS", ml_pi_lds, x >= 32 && x <= 160),
     LDPC_KNOB_INT("ENC_B", enc_b, x == 128 || x == 256),
     LDPC_KNOB_INT("ENC_LIST", enc_list, x == 0 || x == 1),
     {"RS", [](Knobs &k, const char *v) { if (!strcmp(v, "generic")) k.rs_generic = 1; else if (!strcmp(v, "fast")) k.rs_generic = 0; else return false; return true; },
@@ -152,6 +155,7 @@ int scratch_reserve(ldpc_amd_ctx *ctx, Scratch &s, size_t bytes)
         hipError_t e = hipStreamSynchronize(ctx->stream);
         if (e == hipSuccess && ctx->aux_in) e = hipStreamSynchronize(ctx->aux_in);
         if (e == hipSuccess && ctx->aux_out) e = hipStreamSynchronize(ctx->aux_out);
+        if (e == hipSuccess && ctx->aux_ml) e = hipStreamSynchronize(ctx->aux_ml);
         if (e != hipSuccess) return set_error(ctx, LDPC_AMD_EHIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
         (void)hipFree(s.p);
         s.p = nullptr;
@@ -610,8 +614,11 @@ void ldpc_amd_cleanup(ldpc_amd_ctx *ctx)
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->pipe_events)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ml_events)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->aux_in) (void)hipStreamDestroy(ctx->aux_in);
     if (ctx->aux_out) (void)hipStreamDestroy(ctx->aux_out);
+    if (ctx->aux_ml) (void)hipStreamDestroy(ctx->aux_ml);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->ml_head_host) (void)hipHostFree(ctx->ml_head_host);
@@ -627,6 +634,7 @@ int ldpc_amd_set_stream(ldpc_amd_ctx *ctx, void *hip_stream)
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->aux_in) (void)hipStreamSynchronize(ctx->aux_in);
     if (ctx->aux_out) (void)hipStreamSynchronize(ctx->aux_out);
+    if (ctx->aux_ml) (void)hipStreamSynchronize(ctx->aux_ml);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;

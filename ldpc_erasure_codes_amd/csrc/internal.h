@@ -92,6 +92,11 @@ struct Knobs {
     int ml_solve_b = 128;        // ML_SOLVE_B: bytes of every row per solve-kernel workgroup
     long long ml_arena_words = 0;   // ML_ARENA_WORDS: size of the schedule arena in 64-bit words (0 = auto)
     int ml_threads = 0;          // ML_THREADS: threads of the ML kernel's workgroup (0 = 1024 / ML_PACK)
+    int ml_pi = 1;               // ML_PI: packets -- the fast path (ml_pi.inc: peel on + inactivation) before the exact elimination.  1: verified
+                                 // (frames that fail the consistency test are redone exactly: the reference's bytes on ANY input); 2: not
+                                 // verified (the reference's bytes when the received symbols are a codeword with erasures); 0: exact only
+    int ml_pi_lds = 160;         // ML_PI_LDS: KB of LDS per fast-path workgroup (160: one workgroup of up to four frames per CU)
+    int ml_overlap = 1;          // ML_OVERLAP: packets -- the factorisation runs on a second stream beside the packet kernel; 0 = behind it
     int ml_pack = 2;             // ML_PACK: ML-kernel workgroups per CU (1, 2, 3, 4): 1024 / P threads and 160 KB / P of LDS each
     int enc_b = 128;             // ENC_B: encoder piece size (128: two workgroups per CU; 256: the decoder's plan)
     int enc_list = 0;            // ENC_LIST: encoder streams the source rows in the order of their column degree
@@ -116,6 +121,8 @@ struct ldpc_amd_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    hipStream_t aux_ml = nullptr;                      // packets: the ML factorisation beside the packet kernel (created on first use)
+    hipEvent_t ml_events[2] = {nullptr, nullptr};      // fork / join of that stream
     hipStream_t aux_in = nullptr, aux_out = nullptr;   // host-pointer pipeline: H2D / D2H streams (created on first use)
     hipEvent_t pipe_events[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // ... and its events (created once)
     std::string err;

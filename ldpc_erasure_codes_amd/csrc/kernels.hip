@@ -59,12 +59,12 @@ __device__ __forceinline__ void wave_sync()
 __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // residual frames are filed under size classes (ml_list header: count, class counts; then frame ids, then the class lists)
-constexpr int kMlClasses = 16, kMlHdr = 24;
+constexpr int kMlClasses = 16, kMlHdr = 32;
 
 // Diagnostic build only (-DLDPC_AMD_STAMPS, tools/stamp_peel.py): per-phase cycle sums of the peel kernel go to a
 // buffer nothing else reads.  The product build contains no stamp.
 #ifdef LDPC_AMD_STAMPS
-__device__ unsigned long long g_peel_stamps[40];   // [0..15] peel / packet kernel, [16..31] ML kernel, [32..39] ML solve kernel
+__device__ unsigned long long g_peel_stamps[56];   // [0..15] peel / packet kernel, [16..31] ML kernel, [32..39] ML solve kernel, [40..55] ML fast path
 #define LDPC_STAMP(i)                                                                     \
     do {                                                                                  \
         const unsigned long long t__ = __builtin_amdgcn_s_memtime();                      \
@@ -1209,6 +1209,7 @@ __global__ __launch_bounds__(1024) void ldpc_scatter_big_kernel(ScatterArgs a)
 }
 
 #include "ml_kernel.inc"
+#include "ml_pi.inc"
 
 // =================================================================================================
 // Synthetic inputs (role of the FPGA data_in kernel, OpenCL/device/ldpc_erasure_decoder_top.cl:57-120)
@@ -1668,6 +1669,258 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         LDPC_HIP_TRY(ctx, hipMemsetAsync(ctx->biglist.p, 0, 2 * sizeof(int32_t), ctx->stream));   // [0] count, [1] tier 2's work counter
     }
 
+    // ---- the ML stage (a2-a4): prepared before the packet kernel is launched, because in packet mode its pattern-only part --
+    //      the fast path and the factorisation of what the fast path leaves -- can run beside the packet kernel (second stream)
+    MlArgs ma{};
+    PiArgs pi{};
+    int pi_nw = 0, pi_total = 0, grid = 0, total = 0, ml_threads = 0, solve_b = 0;
+    bool ml_overlap = false, ml_prepared = false, ml_front_done = false;
+    hipEvent_t ml_ev = nullptr;
+    auto ml_prepare = [&]() -> int {
+        int rc;
+        ma.code = cd; ma.S = d.S;
+        ma.Spad = fused ? 16 : d.S;
+        ma.ml_list = (const int32_t *)ctx->mllist.p; ma.ml_state = (const uint8_t *)ctx->mlstate.p; ma.nframes = nf;
+        ma.out = d.out; ma.status = d.status;
+        const int maxrow = align_up(cd.m, 16) + 32;
+        ma.maxrow = maxrow;
+        int off = 0;
+        // rlist[3][m] u32; colmap[n] u16 is only alive while rlist[1..2] are not, and shares their bytes
+        ma.lds_rlist = off; ma.lds_colmap = off + 4 * cd.m;
+        // (packets: the same bytes later hold the per-level histogram, 2 m + 4 words, and the slot map, m halfwords)
+        off += align_up(std::max(std::max(12 * cd.m, 4 * cd.m + 2 * cd.n), 4 * (2 * cd.m + 4) + 2 * cd.m + 16), 16);
+        ma.lds_elist = off; off += align_up(2 * cd.m, 16);
+        ma.lds_colv = off; off += align_up(3 * cd.mpad, 16);
+        ma.lds_perm = off; off += align_up(2 * cd.m + 2, 16);
+        ma.lds_iperm = off; off += align_up(2 * cd.m, 16);
+        ma.lds_orow = off; off += align_up(2 * cd.m, 16);
+        ma.lds_plog = off; off += align_up(cd.m, 16);
+        ma.lds_mt = off; off += 8192;
+        ma.lds_lg = off; off += 256;
+        ma.lds_ex = off; off += 1024;
+        ma.lds_misc = off; off += 128 + 4 * kMlClasses;
+        ma.lds_lvl = off; off += align_up(4 * (cd.m + 2), 16);
+        ma.lds_A = off;
+        if (off > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "ML stage: LDS need %d bytes", off);
+        if (cd.m > 4096) return set_error(ctx, LDPC_AMD_EUNSUP, "ML stage: more than 4096 checks (%d)", cd.m);   // 12-bit row fields of the pivot key
+        // ML_PACK = P workgroups per CU (1024 / P threads, 160 KB / P of LDS each): the factorisation is bound by the instructions
+        // all wavefronts of a workgroup issue per column, not by the work in a column, so P small workgroups -- P systems per CU,
+        // their matrices in the global scratch (L2) when they do not fit the LDS share -- issue P times fewer of them per system
+        const int pack = std::max(1, std::min(4, kn.ml_pack));
+        total = std::max(off + 256, (kLdsMax / pack) & ~255);
+        if (total > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "ML stage: LDS need %d bytes", total);
+        ma.capA = (total - off) & ~15;
+        grid = (int)std::min<int64_t>(nf, (int64_t)ctx->sm_count * pack);
+        const size_t perA = (size_t)cd.m * maxrow, perR = fused ? 0 : (size_t)cd.m * d.S;
+        if ((rc = scratch_reserve(ctx, ctx->mlws, (perA + perR) * grid + 256))) return rc;
+        // work counters: [0] frame hand-out counter, [2..3] arena bump pointer (u64), [4] task counter of the solve kernel.  They
+        // sit in the free tail of the residual list's header (ints 18..23), which launch_decode zeroes with that header: one
+        // memset per call less (a call is launch-bound at S = 1)
+        // [1] frames deferred by the launch beside the packet kernel, [5] frame hand-out counter of the fast path (ldpc_ml_pi_kernel)
+        // header ints 24..26: verification failures of the fast path, hand-out counters of the two launches that redo those frames
+        static_assert(kMlHdr >= 27 && 1 + kMlClasses <= 17, "ml_list header: no room for the work counters");
+        ma.work = (int32_t *)ctx->mllist.p + 18;
+        ma.work2 = (int32_t *)ctx->mllist.p + 17;   // hand-out counter of the launch that solves the deferred frames (mode 2)
+        ma.nfail = (int32_t *)ctx->mllist.p + 24;   // frames whose fast-path solution failed the consistency check (not codewords)
+        ma.work3 = (int32_t *)ctx->mllist.p + 25;   // hand-out counter of the launch that factors them again, exactly (mode 3)
+        ma.wsA = (uint8_t *)ctx->mlws.p + 256;
+        ma.wsR = ma.wsA + perA * grid;
+        // packets: the ML kernel factors every residual system on bytes and emits a solve schedule (64-bit ops grouped by
+        // dependency level) into an arena; ldpc_ml_solve_kernel then runs the schedules on LDS-resident row slices.
+        // Frames whose schedule does not fit the arena are solved inside the ML kernel (same bytes, slower).
+        ma.use_solve = (!fused && kn.ml_solve != 0) ? 1 : 0;
+        ma.dbg = kn.ml_dbg;
+        if (ma.use_solve) {
+            solve_b = kn.ml_solve_b;   // A/B knob
+            while (solve_b > 16 && (d.S % solve_b) != 0) solve_b >>= 1;
+            const int tail_sv = align_up(4 * (2 * cd.m + 6), 16) + 8192 + 16 + 4 * kMlClasses;
+            while (solve_b > 16 && cd.m * solve_b + tail_sv > 79 * 1024) solve_b >>= 1;
+            if (cd.m * solve_b + tail_sv > kLdsMax || cd.n > 65535) ma.use_solve = 0;
+        }
+        ma.solve_b = solve_b;
+        if (ma.use_solve) {
+            // The arena follows DEMAND, not the batch size: 16 MB to start with (2 M words); the words the previous call asked for
+            // come back through a pinned host word (copied behind every call, never waited for), and when they exceeded three quarters of
+            // the arena it grows to twice that demand, at most 1 GB.  A call that overflows is still correct -- the frames
+            // that do not fit are solved inside the ML kernel -- so a steady workload is at full speed from its second or third
+            // batch, and a batch message passing completes pins 16 MB instead of 64 KB per frame.
+            size_t words = std::max<size_t>(ctx->ml_arena_words, (size_t)1 << 21);
+            if (ctx->ml_head_host) {
+                const unsigned long long need = *ctx->ml_head_host;   // demand of an earlier call (whatever has landed)
+                if (need > words / 4 * 3) words = std::min<size_t>(std::max<size_t>(words, (size_t)need * 2), (size_t)1 << 27);
+            }
+            if (kn.ml_arena_words >= 1024) words = (size_t)kn.ml_arena_words;   // test knob: a small arena makes some frames fall back
+            ctx->ml_arena_words = kn.ml_arena_words >= 1024 ? ctx->ml_arena_words : words;
+            if ((rc = scratch_reserve(ctx, ctx->mlops, words * 8)) || (rc = scratch_reserve(ctx, ctx->mlrec, (size_t)nf * 32))) return rc;
+            ma.ops = (unsigned long long *)ctx->mlops.p; ma.ops_cap = words;
+            ma.ops_head = (unsigned long long *)(ma.work + 2);
+            ma.rec = (uint32_t *)ctx->mlrec.p;
+        } else if (!fused) {
+            if ((rc = scratch_reserve(ctx, ctx->mlrec, (size_t)nf * 32))) return rc;
+            ma.rec = (uint32_t *)ctx->mlrec.p;   // the fall-back flag is written in either case
+        }
+        ml_threads = kn.ml_threads > 0 ? kn.ml_threads : std::max(256, (1024 / pack) & ~63);
+        LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(ldpc_ml_kernel)));
+        ctx->prof_names[LDPC_AMD_PROF_ML] = "ldpc_ml_kernel";
+        // Packets: the fast path first (ml_pi.inc: peel on, inactivate, small dense system; a wavefront per frame).  It emits
+        // the schedules of the full-rank frames; ldpc_ml_kernel then factors what it left (rank-deficient frames, rec[6] = 0).
+        if (ma.use_solve && kn.ml_pi != 0) {
+            int shared = 8192 + 256 + 1024 + 64;   // multiply tables, log, antilog, size-class counts
+            pi.lds_mt = 0; pi.lds_lg = 8192; pi.lds_ex = 8192 + 256;
+            pi.lds_edges = pi.lds_rowptr = -1;
+            const int rows_bytes = align_up(4 * cd.nnz, 16) + align_up(4 * (cd.m + 1), 16);
+            if (rows_bytes <= 40 * 1024) {   // the code's rows in LDS (every frame walks them a few times); else from global memory
+                pi.lds_edges = shared; pi.lds_rowptr = shared + align_up(4 * cd.nnz, 16);
+                shared += rows_bytes;
+            }
+            int o = 0;
+            pi.o_vinfo = o; o += align_up(2 * cd.n, 16);
+            pi.o_cnt = o; o += align_up(4 * (cd.m + 264), 16);
+            pi.o_lvl = o; o += align_up(4 * cd.m, 16);
+            pi.o_ustate = o; o += align_up(2 * cd.m, 16);
+            pi.o_uvar = o; o += align_up(2 * cd.m, 16);
+            pi.o_stepc = o; o += align_up(2 * cd.m, 16);
+            pi.o_stepi = o; o += align_up(2 * cd.m, 16);
+            pi.o_slvl = o; o += align_up(2 * cd.m, 16);
+            pi.o_sginv = o; o += align_up(cd.m, 16);
+            pi.o_queue = o; o += align_up(2 * cd.m, 16);
+            pi.o_candpiv = o; o += align_up(2 * cd.m, 16);
+            pi.o_inact = o; o += 512;
+            pi.o_sel = o; o += 512;
+            pi.o_sellvl = o; o += 512;
+            pi.o_dlog = o; o += 256;
+            pi.o_misc = o; o += 16 + 512;   // queue tail; the winners of a batch
+            pi.o_av = o;
+            const int budget = std::max(32, std::min(160, kn.ml_pi_lds)) * 1024 - shared;
+            const int av_want = std::min(cd.m * 32, 16 * 1024);
+            pi_nw = std::max(1, std::min(4, budget / (o + av_want)));
+            const int per_wave = (budget / pi_nw) & ~15;
+            if (per_wave >= o + 1024 && cd.maxdeg <= kWave && cd.maxcoldeg <= 16 && cd.m < 0x8000 && cd.n < 0xFFFF) {
+                pi.av_bytes = per_wave - o;
+                pi.lds_wave0 = shared; pi.lds_wave_stride = per_wave;
+                pi_total = shared + pi_nw * per_wave;
+            } else {
+                pi_nw = 0;
+            }
+        }
+        ma.use_pi = pi_nw > 0 ? 1 : 0;
+        if (pi_nw > 0) {
+            pi.code = cd; pi.ml_list = ma.ml_list; pi.nframes = nf; pi.ml_state = ma.ml_state; pi.work = ma.work + 5;
+            pi.status = d.status; pi.ops = ma.ops; pi.ops_cap = ma.ops_cap; pi.ops_head = ma.ops_head; pi.rec = ma.rec;
+            pi.solve_b = solve_b;
+            pi.verify = kn.ml_pi == 1 ? 1 : 0;
+            LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(ldpc_ml_pi_kernel)));
+        }
+        // The factorisation needs the erasure pattern only: in packet mode (schedules, not payload) it runs on a second stream
+        // beside the packet kernel.  A frame whose schedule does not fit the arena is DEFERRED there (rec[5] = 2, ma.work[1] counts
+        // them) and solved by a second launch behind the packet kernel -- its in-kernel solve reads the payload.
+        // (Only with the fast path: beside the packet kernel the factorisation of EVERY residual frame takes as much from the packet
+        // kernel as it saves -- 6.87 against 6.94 ms on cfg 3 -- while the few frames the fast path leaves disappear behind it.)
+        ml_overlap = ma.use_solve && use_scatter && pi_nw > 0 && kn.ml_overlap != 0;
+        if (ml_overlap) {
+            if (!ctx->aux_ml) LDPC_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_ml, hipStreamNonBlocking));
+            for (hipEvent_t &e : ctx->ml_events)
+                if (!e) LDPC_HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        return LDPC_AMD_OK;
+    };
+    // fast path + factorisation (pattern only in packet mode)
+    auto ml_front = [&]() -> int {
+        int rc;
+        (void)rc;
+        ml_ev = prof_begin(ctx);
+        if (pi_nw > 0) {
+            const int wgs_per_cu = std::max(1, kLdsMax / pi_total);
+            const int pgrid = (int)std::min<int64_t>((nf + pi_nw - 1) / pi_nw, (int64_t)ctx->sm_count * wgs_per_cu);
+            hipLaunchKernelGGL(ldpc_ml_pi_kernel, dim3(pgrid), dim3(64 * pi_nw), (size_t)pi_total, ctx->stream, pi);
+            LDPC_HIP_TRY(ctx, hipGetLastError());
+        }
+        hipStream_t st = ctx->stream;
+        if (ml_overlap) {
+            prof_end(ctx, LDPC_AMD_PROF_ML, ml_ev);   // (the stage's share of the main stream is timed in two pieces)
+            ml_ev = nullptr;
+            LDPC_HIP_TRY(ctx, hipEventRecord(ctx->ml_events[0], ctx->stream));
+            LDPC_HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_ml, ctx->ml_events[0], 0));
+            st = ctx->aux_ml;
+        }
+        ma.mode = ml_overlap ? 1 : 0;
+        hipLaunchKernelGGL(ldpc_ml_kernel, dim3(grid), dim3(ml_threads), (size_t)total, st, ma);
+        LDPC_HIP_TRY(ctx, hipGetLastError());
+        if (ml_overlap) LDPC_HIP_TRY(ctx, hipEventRecord(ctx->ml_events[1], ctx->aux_ml));
+        return LDPC_AMD_OK;
+    };
+    // what needs the payload: deferred frames, the solve kernel
+    auto ml_back = [&]() -> int {
+        if (ml_overlap) {
+            ml_ev = prof_begin(ctx);
+            LDPC_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ml_events[1], 0));
+            ma.mode = 2;   // the deferred frames only (none, normally: the kernel leaves after one load)
+            hipLaunchKernelGGL(ldpc_ml_kernel, dim3(grid), dim3(ml_threads), (size_t)total, ctx->stream, ma);
+            LDPC_HIP_TRY(ctx, hipGetLastError());
+        }
+        if (ma.use_solve && kn.ml_solve != 2) {   // =2: diagnostic, schedules emitted but not run (timing of the factor part)
+            MlSolveArgs sv{};
+            sv.code = cd; sv.S = d.S; sv.nslices = d.S / solve_b; sv.nframes = nf; sv.ml_list = ma.ml_list; sv.rec = ma.rec; sv.ops = ma.ops;
+            sv.out = d.out; sv.work = ma.work + 4;
+            sv.dbg = ma.dbg;
+            sv.nfail = ma.nfail; sv.round = 1;
+            int o = 8192 + cd.m * solve_b;   // multiply tables first (kMlSlot0), then the slots
+            sv.lds_tab = o; o += align_up(4 * (2 * cd.m + 6), 16);
+            sv.lds_mt = 0;
+            sv.lds_misc = o; o += 16 + 4 * kMlClasses;
+            const int per_cu = std::max(1, std::min(4, kLdsMax / o));
+            const dim3 sg((unsigned)std::min<int64_t>(nf * sv.nslices, (int64_t)ctx->sm_count * per_cu));
+#define LDPC_ML_SOLVE(LPRV)                                                                                   \
+    {                                                                                                        \
+        auto sfn = ldpc_ml_solve_kernel<LPRV>;                                                               \
+        LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(sfn)));                               \
+        hipLaunchKernelGGL(sfn, sg, dim3(512), (size_t)o, ctx->stream, sv);                                  \
+    }
+            {
+                char nm[64];
+                snprintf(nm, sizeof(nm), "ldpc_ml_solve_kernel<%d>", solve_b / 16);
+                ctx->prof_names[LDPC_AMD_PROF_ML_SOLVE] = nm;
+            }
+            hipEvent_t evs = prof_begin(ctx, 2);
+            switch (solve_b) {
+                case 128: LDPC_ML_SOLVE(8) break;
+                case 64: LDPC_ML_SOLVE(4) break;
+                case 32: LDPC_ML_SOLVE(2) break;
+                default: LDPC_ML_SOLVE(1) break;
+            }
+            prof_end(ctx, LDPC_AMD_PROF_ML_SOLVE, evs);
+            LDPC_HIP_TRY(ctx, hipGetLastError());
+            if (pi_nw > 0 && pi.verify) {
+                // Verified fast path: a frame whose received symbols are not a codeword makes the residual system INCONSISTENT, and
+                // then the bytes depend on which equations a solver uses.  The fast-path schedules therefore also evaluate the
+                // equations they did not use; the solve kernel flags a frame with a non-zero one (rec[7], nfail), and these two
+                // launches -- which leave after one load when nothing was flagged -- redo such frames in the reference's order.
+                ma.mode = 3;
+                hipLaunchKernelGGL(ldpc_ml_kernel, dim3(grid), dim3(ml_threads), (size_t)total, ctx->stream, ma);
+                LDPC_HIP_TRY(ctx, hipGetLastError());
+                sv.round = 2; sv.work = (int32_t *)ctx->mllist.p + 26;
+                switch (solve_b) {
+                    case 128: LDPC_ML_SOLVE(8) break;
+                    case 64: LDPC_ML_SOLVE(4) break;
+                    case 32: LDPC_ML_SOLVE(2) break;
+                    default: LDPC_ML_SOLVE(1) break;
+                }
+                LDPC_HIP_TRY(ctx, hipGetLastError());
+            }
+#undef LDPC_ML_SOLVE
+        }
+        prof_end(ctx, LDPC_AMD_PROF_ML, ml_ev);
+        if (ma.use_solve) {   // this call's arena demand -> pinned host word, read by a later call (no wait here)
+            if (!ctx->ml_head_host) {
+                if (hipHostMalloc((void **)&ctx->ml_head_host, 64, hipHostMallocDefault) != hipSuccess) ctx->ml_head_host = nullptr;
+                else *ctx->ml_head_host = 0;
+            }
+            if (ctx->ml_head_host)
+                LDPC_HIP_TRY(ctx, hipMemcpyAsync(ctx->ml_head_host, ma.ops_head, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        return LDPC_AMD_OK;
+    };
+
     PeelArgs pa{};
     pa.code = cd; pa.lds = L; pa.nframes = nf; pa.sym = d.sym; pa.erased = d.erased; pa.in_rows = d.in_rows;
     pa.max_sweeps = d.max_sweeps; pa.do_ml = d.do_ml; pa.out = d.out;
@@ -1703,6 +1956,14 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         LDPC_HIP_TRY(ctx, launch_peel_t<false>(pa, wpb, ctx->stream));
         prof_end(ctx, LDPC_AMD_PROF_PEEL, ev);
 
+        if (d.do_ml) {
+            if ((rc = ml_prepare())) return rc;
+            ml_prepared = true;
+            if (ml_overlap) {
+                if ((rc = ml_front())) return rc;
+                ml_front_done = true;
+            }
+        }
         if (use_scatter) {
             ScatterArgs sa{};
             sa.code = cd; sa.S = d.S; sa.nslices = plan.nslices; sa.nframes = nf; sa.sym = d.sym; sa.erased = d.erased; sa.out = d.out;
@@ -1727,133 +1988,9 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     }
 
     if (d.do_ml) {
-        MlArgs ma{};
-        ma.code = cd; ma.S = d.S;
-        ma.Spad = fused ? 16 : d.S;
-        ma.ml_list = (const int32_t *)ctx->mllist.p; ma.ml_state = (const uint8_t *)ctx->mlstate.p; ma.nframes = nf;
-        ma.out = d.out; ma.status = d.status;
-        const int maxrow = align_up(cd.m, 16) + 32;
-        ma.maxrow = maxrow;
-        int off = 0;
-        // rlist[3][m] u32; colmap[n] u16 is only alive while rlist[1..2] are not, and shares their bytes
-        ma.lds_rlist = off; ma.lds_colmap = off + 4 * cd.m;
-        // (packets: the same bytes later hold the per-level histogram, 2 m + 4 words, and the slot map, m halfwords)
-        off += align_up(std::max(std::max(12 * cd.m, 4 * cd.m + 2 * cd.n), 4 * (2 * cd.m + 4) + 2 * cd.m + 16), 16);
-        ma.lds_elist = off; off += align_up(2 * cd.m, 16);
-        ma.lds_colv = off; off += align_up(3 * cd.mpad, 16);
-        ma.lds_perm = off; off += align_up(2 * cd.m + 2, 16);
-        ma.lds_iperm = off; off += align_up(2 * cd.m, 16);
-        ma.lds_orow = off; off += align_up(2 * cd.m, 16);
-        ma.lds_plog = off; off += align_up(cd.m, 16);
-        ma.lds_mt = off; off += 8192;
-        ma.lds_lg = off; off += 256;
-        ma.lds_ex = off; off += 1024;
-        ma.lds_misc = off; off += 128 + 4 * kMlClasses;
-        ma.lds_lvl = off; off += align_up(4 * (cd.m + 2), 16);
-        ma.lds_A = off;
-        if (off > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "ML stage: LDS need %d bytes", off);
-        if (cd.m > 4096) return set_error(ctx, LDPC_AMD_EUNSUP, "ML stage: more than 4096 checks (%d)", cd.m);   // 12-bit row fields of the pivot key
-        // ML_PACK = P workgroups per CU (1024 / P threads, 160 KB / P of LDS each): the factorisation is bound by the instructions
-        // all wavefronts of a workgroup issue per column, not by the work in a column, so P small workgroups -- P systems per CU,
-        // their matrices in the global scratch (L2) when they do not fit the LDS share -- issue P times fewer of them per system
-        const int pack = std::max(1, std::min(4, kn.ml_pack));
-        const int total = std::max(off + 256, (kLdsMax / pack) & ~255);
-        if (total > kLdsMax) return set_error(ctx, LDPC_AMD_EUNSUP, "ML stage: LDS need %d bytes", total);
-        ma.capA = (total - off) & ~15;
-        int grid = (int)std::min<int64_t>(nf, (int64_t)ctx->sm_count * pack);
-        const size_t perA = (size_t)cd.m * maxrow, perR = fused ? 0 : (size_t)cd.m * d.S;
-        if ((rc = scratch_reserve(ctx, ctx->mlws, (perA + perR) * grid + 256))) return rc;
-        // work counters: [0] frame hand-out counter, [2..3] arena bump pointer (u64), [4] task counter of the solve kernel.  They
-        // sit in the free tail of the residual list's header (ints 18..23), which launch_decode zeroes with that header: one
-        // memset per call less (a call is launch-bound at S = 1)
-        static_assert(kMlHdr >= 18 + 6 && 1 + kMlClasses <= 18, "ml_list header: no room for the work counters");
-        ma.work = (int32_t *)ctx->mllist.p + 18;
-        ma.wsA = (uint8_t *)ctx->mlws.p + 256;
-        ma.wsR = ma.wsA + perA * grid;
-        // packets: the ML kernel factors every residual system on bytes and emits a solve schedule (64-bit ops grouped by
-        // dependency level) into an arena; ldpc_ml_solve_kernel then runs the schedules on LDS-resident row slices.
-        // Frames whose schedule does not fit the arena are solved inside the ML kernel (same bytes, slower).
-        ma.use_solve = (!fused && kn.ml_solve != 0) ? 1 : 0;
-        ma.dbg = kn.ml_dbg;
-        int solve_b = 0;
-        if (ma.use_solve) {
-            solve_b = kn.ml_solve_b;   // A/B knob
-            while (solve_b > 16 && (d.S % solve_b) != 0) solve_b >>= 1;
-            const int tail_sv = align_up(4 * (2 * cd.m + 6), 16) + 8192 + 16 + 4 * kMlClasses;
-            while (solve_b > 16 && cd.m * solve_b + tail_sv > 79 * 1024) solve_b >>= 1;
-            if (cd.m * solve_b + tail_sv > kLdsMax || cd.n > 65535) ma.use_solve = 0;
-        }
-        ma.solve_b = solve_b;
-        if (ma.use_solve) {
-            // The arena follows DEMAND, not the batch size: 16 MB to start with (2 M words); the words the previous call asked for
-            // come back through a pinned host word (copied behind every call, never waited for), and when they exceeded three quarters of
-            // the arena it grows to twice that demand, at most 1 GB.  A call that overflows is still correct -- the frames
-            // that do not fit are solved inside the ML kernel -- so a steady workload is at full speed from its second or third
-            // batch, and a batch message passing completes pins 16 MB instead of 64 KB per frame.
-            size_t words = std::max<size_t>(ctx->ml_arena_words, (size_t)1 << 21);
-            if (ctx->ml_head_host) {
-                const unsigned long long need = *ctx->ml_head_host;   // demand of an earlier call (whatever has landed)
-                if (need > words / 4 * 3) words = std::min<size_t>(std::max<size_t>(words, (size_t)need * 2), (size_t)1 << 27);
-            }
-            if (kn.ml_arena_words >= 1024) words = (size_t)kn.ml_arena_words;   // test knob: a small arena makes some frames fall back
-            ctx->ml_arena_words = kn.ml_arena_words >= 1024 ? ctx->ml_arena_words : words;
-            if ((rc = scratch_reserve(ctx, ctx->mlops, words * 8)) || (rc = scratch_reserve(ctx, ctx->mlrec, (size_t)nf * 32))) return rc;
-            ma.ops = (unsigned long long *)ctx->mlops.p; ma.ops_cap = words;
-            ma.ops_head = (unsigned long long *)(ma.work + 2);
-            ma.rec = (uint32_t *)ctx->mlrec.p;
-        } else if (!fused) {
-            if ((rc = scratch_reserve(ctx, ctx->mlrec, (size_t)nf * 32))) return rc;
-            ma.rec = (uint32_t *)ctx->mlrec.p;   // the fall-back flag is written in either case
-        }
-        const int ml_threads = kn.ml_threads > 0 ? kn.ml_threads : std::max(256, (1024 / pack) & ~63);
-        auto kfn = ldpc_ml_kernel;
-        LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(kfn)));
-        ctx->prof_names[LDPC_AMD_PROF_ML] = "ldpc_ml_kernel";
-        hipEvent_t ev = prof_begin(ctx);
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(ml_threads), (size_t)total, ctx->stream, ma);
-        LDPC_HIP_TRY(ctx, hipGetLastError());
-        if (ma.use_solve && kn.ml_solve != 2) {   // =2: diagnostic, schedules emitted but not run (timing of the factor part)
-            MlSolveArgs sv{};
-            sv.code = cd; sv.S = d.S; sv.nslices = d.S / solve_b; sv.nframes = nf; sv.ml_list = ma.ml_list; sv.rec = ma.rec; sv.ops = ma.ops;
-            sv.out = d.out; sv.work = ma.work + 4;
-            sv.dbg = ma.dbg;
-            int o = 8192 + cd.m * solve_b;   // multiply tables first (kMlSlot0), then the slots
-            sv.lds_tab = o; o += align_up(4 * (2 * cd.m + 6), 16);
-            sv.lds_mt = 0;
-            sv.lds_misc = o; o += 16 + 4 * kMlClasses;
-            const int per_cu = std::max(1, std::min(4, kLdsMax / o));
-            const dim3 sg((unsigned)std::min<int64_t>(nf * sv.nslices, (int64_t)ctx->sm_count * per_cu));
-#define LDPC_ML_SOLVE(LPRV)                                                                                   \
-    {                                                                                                        \
-        auto sfn = ldpc_ml_solve_kernel<LPRV>;                                                               \
-        LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(sfn)));                               \
-        hipLaunchKernelGGL(sfn, sg, dim3(512), (size_t)o, ctx->stream, sv);                                  \
-    }
-            {
-                char nm[64];
-                snprintf(nm, sizeof(nm), "ldpc_ml_solve_kernel<%d>", solve_b / 16);
-                ctx->prof_names[LDPC_AMD_PROF_ML_SOLVE] = nm;
-            }
-            hipEvent_t evs = prof_begin(ctx, 2);
-            switch (solve_b) {
-                case 128: LDPC_ML_SOLVE(8) break;
-                case 64: LDPC_ML_SOLVE(4) break;
-                case 32: LDPC_ML_SOLVE(2) break;
-                default: LDPC_ML_SOLVE(1) break;
-            }
-#undef LDPC_ML_SOLVE
-            prof_end(ctx, LDPC_AMD_PROF_ML_SOLVE, evs);
-            LDPC_HIP_TRY(ctx, hipGetLastError());
-        }
-        prof_end(ctx, LDPC_AMD_PROF_ML, ev);
-        if (ma.use_solve) {   // this call's arena demand -> pinned host word, read by a later call (no wait here)
-            if (!ctx->ml_head_host) {
-                if (hipHostMalloc((void **)&ctx->ml_head_host, 64, hipHostMallocDefault) != hipSuccess) ctx->ml_head_host = nullptr;
-                else *ctx->ml_head_host = 0;
-            }
-            if (ctx->ml_head_host)
-                LDPC_HIP_TRY(ctx, hipMemcpyAsync(ctx->ml_head_host, ma.ops_head, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-        }
+        if (!ml_prepared && (rc = ml_prepare())) return rc;
+        if (!ml_front_done && (rc = ml_front())) return rc;
+        if ((rc = ml_back())) return rc;
     }
     return LDPC_AMD_OK;
 }
@@ -2048,9 +2185,9 @@ int launch_fpga_halves(ldpc_amd_ctx *ctx, const DevCode &code, int64_t nframes, 
 extern "C" int ldpc_amd_debug_peel_stamps(ldpc_amd_ctx *ctx, unsigned long long *out32, int reset)
 {
     LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    LDPC_HIP_TRY(ctx, hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_peel_stamps), 40 * sizeof(unsigned long long)));
+    LDPC_HIP_TRY(ctx, hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_peel_stamps), 56 * sizeof(unsigned long long)));
     if (reset) {
-        unsigned long long z[40] = {0};
+        unsigned long long z[56] = {0};
         LDPC_HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_peel_stamps), z, sizeof(z)));
     }
     return LDPC_AMD_OK;

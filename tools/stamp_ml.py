@@ -47,7 +47,7 @@ def main():
         ctx.synchronize()
         rs_c = rs.cpu().numpy()
         order = np.argsort(rs_c)
-        buf = (C.c_ulonglong * 40)()
+        buf = (C.c_ulonglong * 56)()
         for E in (100, 200, 300, 400):
             j = int(order[np.searchsorted(rs_c[order], E, side="left")])
             s1, e1 = cw[j:j + 1].contiguous(), era[j:j + 1].contiguous()

@@ -42,7 +42,7 @@ def main():
         else:   # the BASELINE cfg 3 channel of bench.py (frames with E0 >= n-k are simply left undecodable here)
             ctx.synth_erasures_bursty(20261005 + 1, 0, F, n, 0.13, 0.8, 10.0, era)
         print(f"--- S={S} channel={channel}")
-        buf = (C.c_ulonglong * 40)()
+        buf = (C.c_ulonglong * 56)()
         L.ldpc_amd_debug_peel_stamps(ctx._h, buf, 1)
         reps = 5
         for _ in range(reps):
