@@ -516,6 +516,21 @@ def run_cfg3(g, args, S):
                      f"{cw.shape[0]} with E0 < n-k decoded (the rest skipped as in ErasureCodes_NonBinaryLDPCSim.m:216)")
     s["frames_skipped_E0_ge_m"] = int((~keep).sum())
     s["sample"] = pick_samples(r, sym, era, True)
+    if S > 1:
+        # the ML stage's other modes on the same batch (ML_PI knob): 0 = exact elimination only (round 2's
+        # path), 2 = fast path without the consistency test (for callers that know their symbols are codewords with erasures).
+        # The line above is the default, 1: fast path + consistency test -- the reference's bytes on any input.
+        s["ml_stage_mode"] = "ML_PI=1 (default): fast path with consistency test, exact elimination for what it leaves or flags"
+        modes = {}
+        for name, val in (("ML_PI=0 exact elimination only", "0"), ("ML_PI=2 fast path, no consistency test", "2")):
+            g.ctx.configure("LDPC_AMD_ML_PI", val)
+            rm = g.time_decode(h, sym, era, 4, 2)
+            sm = summarize(g, rm, cw, n, k, S, 4, cw.shape[0])
+            modes[name] = {"ms_per_step": sm["ms_per_step"], "roofline_frac": sm["roofline_frac"], "verified": sm["verified"],
+                           "same_bytes_as_default": bool(torch.equal(rm["out"], r["out"]))}
+            del rm
+        g.ctx.configure("LDPC_AMD_ML_PI", None)
+        s["ml_stage_other_modes"] = modes
     del cw, sym, era, r
     torch.cuda.empty_cache()
     return s

@@ -95,8 +95,11 @@ struct Knobs {
     int ml_pi = 1;               // ML_PI: packets -- the fast path (ml_pi.inc: peel on + inactivation) before the exact elimination.  1: verified
                                  // (frames that fail the consistency test are redone exactly: the reference's bytes on ANY input); 2: not
                                  // verified (the reference's bytes when the received symbols are a codeword with erasures); 0: exact only
+    int ml_pi_imax = 256;        // ML_PI_IMAX: fast path -- frames that need more inactivations than this go to the exact elimination
+    int ml_pi_waves = 4;         // ML_PI_WAVES: fast path -- at most this many wavefronts (frames) per workgroup
     int ml_pi_lds = 160;         // ML_PI_LDS: KB of LDS per fast-path workgroup (160: one workgroup of up to four frames per CU)
-    int ml_overlap = 1;          // ML_OVERLAP: packets -- the factorisation runs on a second stream beside the packet kernel; 0 = behind it
+    int ml_overlap_prio = 0;     // ML_OVERLAP_PRIO: 1 = that second stream has the lowest priority (measured slower: 5.67 against 5.45 ms on cfg 3)
+    int ml_overlap = 2;          // ML_OVERLAP: packets -- the factorisation runs on a second stream beside the packet kernel; 0 = behind it
     int ml_pack = 2;             // ML_PACK: ML-kernel workgroups per CU (1, 2, 3, 4): 1024 / P threads and 160 KB / P of LDS each
     int enc_b = 128;             // ENC_B: encoder piece size (128: two workgroups per CU; 256: the decoder's plan)
     int enc_list = 0;            // ENC_LIST: encoder streams the source rows in the order of their column degree

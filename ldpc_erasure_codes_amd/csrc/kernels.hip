@@ -1793,7 +1793,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             pi.o_av = o;
             const int budget = std::max(32, std::min(160, kn.ml_pi_lds)) * 1024 - shared;
             const int av_want = std::min(cd.m * 32, 16 * 1024);
-            pi_nw = std::max(1, std::min(4, budget / (o + av_want)));
+            pi_nw = std::max(1, std::min(std::max(1, std::min(4, kn.ml_pi_waves)), budget / (o + av_want)));
             const int per_wave = (budget / pi_nw) & ~15;
             if (per_wave >= o + 1024 && cd.maxdeg <= kWave && cd.maxcoldeg <= 16 && cd.m < 0x8000 && cd.n < 0xFFFF) {
                 pi.av_bytes = per_wave - o;
@@ -1809,6 +1809,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             pi.status = d.status; pi.ops = ma.ops; pi.ops_cap = ma.ops_cap; pi.ops_head = ma.ops_head; pi.rec = ma.rec;
             pi.solve_b = solve_b;
             pi.verify = kn.ml_pi == 1 ? 1 : 0;
+            pi.imax = kn.ml_pi_imax;
             LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(ldpc_ml_pi_kernel)));
         }
         // The factorisation needs the erasure pattern only: in packet mode (schedules, not payload) it runs on a second stream
@@ -1818,7 +1819,11 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         // kernel as it saves -- 6.87 against 6.94 ms on cfg 3 -- while the few frames the fast path leaves disappear behind it.)
         ml_overlap = ma.use_solve && use_scatter && pi_nw > 0 && kn.ml_overlap != 0;
         if (ml_overlap) {
-            if (!ctx->aux_ml) LDPC_HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->aux_ml, hipStreamNonBlocking));
+            if (!ctx->aux_ml) {   // lowest priority: its kernels fill the gaps the packet kernel leaves, not the other way round
+                int lo = 0, hi = 0;
+                LDPC_HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&lo, &hi));
+                LDPC_HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->aux_ml, hipStreamNonBlocking, kn.ml_overlap_prio ? lo : 0));
+            }
             for (hipEvent_t &e : ctx->ml_events)
                 if (!e) LDPC_HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
@@ -1828,21 +1833,26 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     auto ml_front = [&]() -> int {
         int rc;
         (void)rc;
-        ml_ev = prof_begin(ctx);
-        if (pi_nw > 0) {
-            const int wgs_per_cu = std::max(1, kLdsMax / pi_total);
-            const int pgrid = (int)std::min<int64_t>((nf + pi_nw - 1) / pi_nw, (int64_t)ctx->sm_count * wgs_per_cu);
-            hipLaunchKernelGGL(ldpc_ml_pi_kernel, dim3(pgrid), dim3(64 * pi_nw), (size_t)pi_total, ctx->stream, pi);
-            LDPC_HIP_TRY(ctx, hipGetLastError());
-        }
+        // (profiling: LDPC_AMD_PROF_ML is the stage's share of the MAIN stream.  With the fast path and the factorisation both beside
+        // the packet kernel that is ml_back alone; with ML_OVERLAP=1 it comes in two pieces, i.e. two launches of the kind per call)
+        ml_ev = (ml_overlap && kn.ml_overlap == 2) ? nullptr : prof_begin(ctx);
         hipStream_t st = ctx->stream;
-        if (ml_overlap) {
-            prof_end(ctx, LDPC_AMD_PROF_ML, ml_ev);   // (the stage's share of the main stream is timed in two pieces)
+        auto fork = [&]() -> int {
+            prof_end(ctx, LDPC_AMD_PROF_ML, ml_ev);
             ml_ev = nullptr;
             LDPC_HIP_TRY(ctx, hipEventRecord(ctx->ml_events[0], ctx->stream));
             LDPC_HIP_TRY(ctx, hipStreamWaitEvent(ctx->aux_ml, ctx->ml_events[0], 0));
             st = ctx->aux_ml;
+            return LDPC_AMD_OK;
+        };
+        if (ml_overlap && kn.ml_overlap == 2 && (rc = fork())) return rc;   // =2: the fast path beside the packet kernel too
+        if (pi_nw > 0) {
+            const int wgs_per_cu = std::max(1, kLdsMax / pi_total);
+            const int pgrid = (int)std::min<int64_t>((nf + pi_nw - 1) / pi_nw, (int64_t)ctx->sm_count * wgs_per_cu);
+            hipLaunchKernelGGL(ldpc_ml_pi_kernel, dim3(pgrid), dim3(64 * pi_nw), (size_t)pi_total, st, pi);
+            LDPC_HIP_TRY(ctx, hipGetLastError());
         }
+        if (ml_overlap && kn.ml_overlap != 2 && (rc = fork())) return rc;
         ma.mode = ml_overlap ? 1 : 0;
         hipLaunchKernelGGL(ldpc_ml_kernel, dim3(grid), dim3(ml_threads), (size_t)total, st, ma);
         LDPC_HIP_TRY(ctx, hipGetLastError());

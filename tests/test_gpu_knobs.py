@@ -30,6 +30,12 @@ KNOBS = [
     ("LDPC_AMD_ML_ARENA_WORDS", ["20000"]),
     ("LDPC_AMD_ML_THREADS", ["256", "512", "768"]),
     ("LDPC_AMD_ML_PACK", ["1", "3", "4"]),
+    ("LDPC_AMD_ML_PI", ["0", "2"]),                 # (=2, unverified: same bytes because this batch's symbols ARE codewords)
+    ("LDPC_AMD_ML_OVERLAP", ["0", "1"]),
+    ("LDPC_AMD_ML_OVERLAP_PRIO", ["1"]),
+    ("LDPC_AMD_ML_PI_IMAX", ["0", "3", "17"]),
+    ("LDPC_AMD_ML_PI_LDS", ["64", "96"]),
+    ("LDPC_AMD_ML_PI_WAVES", ["1", "2"]),
     ("LDPC_AMD_RS", ["generic"]),
 ]
 

@@ -1,0 +1,142 @@
+"""The ML stage's fast path in packet mode (csrc/ml_pi.inc: peel on + inactivation, ML_PI knob) on the GPU, through the C-ABI:
+  * codewords with erasures (bursty channel of BASELINE cfg 3): every mode -- exact only, verified fast path, unverified fast
+    path; factorisation behind / beside the packet kernel -- returns the oracle's bytes, sweeps, residuals and status words,
+    rank-deficient frames included;
+  * received symbols that are NOT codewords: the verified fast path (the default) still equals the oracle on every frame -- its
+    consistency test sends such frames to the exact elimination -- while the unverified one does not (that is what the test is
+    for, and why ML_PI=2 is opt-in);
+  * the (4000,2000) code, whose rows do not fit the fast path's LDS staging (read from global memory), and a schedule arena too
+    small for the batch (frames deferred behind the packet kernel)."""
+import numpy as np
+import pytest
+
+from ldpc_erasure_codes_amd import api, codes, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def _reset(ctx):
+    for k in ("ML_PI", "ML_OVERLAP", "ML_ARENA_WORDS", "ML_PI_IMAX"):
+        ctx.configure("LDPC_AMD_" + k, None)
+
+
+def _bursty_batch(ctx, h, code, F, S, seed):
+    src = synth.source(seed, 0, F, code.k, S)
+    cw = ctx.encode(h, src)
+    era = synth.erasures_bursty(seed + 1, 0, 3 * F, code.n, 0.13, 0.8, 10.0)
+    era = np.ascontiguousarray(era[era.sum(axis=1) < code.n - code.k][:F])
+    assert era.shape[0] == F
+    sym = cw.copy()
+    sym[era.astype(bool)] = 0xA5
+    return cw, sym, era
+
+
+def _oracle_frames(oc, sym, era, frames):
+    res = {}
+    for f in frames:
+        o_out, _, o_it, info, rc = oc.decode_packets(sym[f], era[f])
+        want = 0 if info[0] == 0 else (3 if (rc == -2 or not info[1]) else (2 if info[2] else 1))
+        res[f] = (o_out, o_it, int(info[0]), want)
+    return res
+
+
+def test_every_mode_equals_the_oracle_on_codewords(ctx, oracle, code_a):
+    h = ctx.load_builtin_code(1, codes.DEFAULT_COEF_SEED[1])
+    oc = oracle.OracleCode(code_a)
+    F, S = 160, 64
+    cw, sym, era = _bursty_batch(ctx, h, code_a, F, S, 5150)
+    _reset(ctx)
+    try:
+        ref = ctx.decode(h, sym, era)
+        out0, sw0, res0, st0 = ref
+        assert (st0 == 1).sum() >= 20 and (st0 == 2).sum() >= 1, np.bincount(st0)   # ML solved, and rank-deficient ones
+        ml = np.flatnonzero(st0 >= 1)
+        check = list(ml[:: max(1, len(ml) // 24)]) + list(np.flatnonzero(st0 == 2))[:4]
+        for f, (o_out, o_it, o_res, want) in _oracle_frames(oc, sym, era, check).items():
+            assert sw0[f] == o_it and res0[f] == o_res and st0[f] == want, f
+            assert np.array_equal(out0[f], o_out), f
+        assert np.array_equal(out0[st0 <= 1], cw[st0 <= 1])
+        for pi in ("0", "1", "2"):
+            for ov in ("0", "1", "2"):
+                ctx.configure("LDPC_AMD_ML_PI", pi)
+                ctx.configure("LDPC_AMD_ML_OVERLAP", ov)
+                got = ctx.decode(h, sym, era)
+                for a_, b_, what in zip(got, ref, ("out", "sweeps", "residual", "status")):
+                    assert np.array_equal(a_, b_), (pi, ov, what)
+    finally:
+        _reset(ctx)
+
+
+def test_symbols_that_are_not_codewords(ctx, oracle, code_a):
+    h = ctx.load_builtin_code(1, codes.DEFAULT_COEF_SEED[1])
+    oc = oracle.OracleCode(code_a)
+    F, S = 96, 32
+    cw, sym, era = _bursty_batch(ctx, h, code_a, F, S, 6260)
+    rng = np.random.default_rng(7)
+    for f in range(F // 2, F):                      # second half: three received symbols of every frame corrupted
+        known = np.flatnonzero(era[f] == 0)
+        for j in rng.choice(known, size=3, replace=False):
+            sym[f, j] ^= rng.integers(1, 256, size=S, dtype=np.uint8)
+    _reset(ctx)
+    try:
+        ctx.configure("LDPC_AMD_ML_PI", "0")
+        exact = ctx.decode(h, sym, era)
+        ctx.configure("LDPC_AMD_ML_PI", "1")
+        verified = ctx.decode(h, sym, era)
+        ctx.configure("LDPC_AMD_ML_PI", "2")
+        unverified = ctx.decode(h, sym, era)
+        for a_, b_, what in zip(verified, exact, ("out", "sweeps", "residual", "status")):
+            assert np.array_equal(a_, b_), what
+        st = exact[3]
+        ml_bad = [f for f in range(F // 2, F) if st[f] == 1]
+        assert len(ml_bad) >= 8
+        for f, (o_out, o_it, o_res, want) in _oracle_frames(oc, sym, era, ml_bad[:12]).items():
+            assert verified[1][f] == o_it and verified[2][f] == o_res and verified[3][f] == want, f
+            assert np.array_equal(verified[0][f], o_out), f
+        # the unverified mode is only for inputs known to be codewords: on these frames it returns other bytes
+        differs = [f for f in ml_bad if not np.array_equal(unverified[0][f], exact[0][f])]
+        assert differs, "the corrupted frames should make the unverified fast path visible"
+        good = [f for f in range(F // 2) if st[f] <= 1]
+        assert np.array_equal(unverified[0][good], exact[0][good])
+    finally:
+        _reset(ctx)
+
+
+def test_code_b_and_a_small_arena(ctx, oracle):
+    code_b = codes.load_builtin(2, codes.DEFAULT_COEF_SEED[2])
+    h = ctx.load_builtin_code(2, codes.DEFAULT_COEF_SEED[2])
+    oc = oracle.OracleCode(code_b)
+    F, S = 40, 16
+    src = synth.source(99, 0, F, code_b.k, S)
+    cw = ctx.encode(h, src)
+    pers = np.linspace(0.40, 0.52, F)               # around the (4000,2000) code's thresholds: sweeps cap, ML, rank deficiency
+    era = np.concatenate([synth.erasures_uniform(200 + i, i, 1, code_b.n, float(p)) for i, p in enumerate(pers)])
+    sym = cw.copy()
+    sym[era.astype(bool)] = 0x3C
+    _reset(ctx)
+    try:
+        ref = ctx.decode(h, sym, era)
+        st = ref[3]
+        assert (st >= 1).sum() >= 6, np.bincount(st)
+        ml = list(np.flatnonzero(st >= 1))[:8]
+        for f, (o_out, o_it, o_res, want) in _oracle_frames(oc, sym, era, ml).items():
+            assert ref[1][f] == o_it and ref[2][f] == o_res and st[f] == want, f
+            if want != 3:
+                assert np.array_equal(ref[0][f], o_out), f
+        for knobs in ({"ML_PI": "0"}, {"ML_ARENA_WORDS": "30000"}, {"ML_ARENA_WORDS": "30000", "ML_OVERLAP": "1"},
+                      {"ML_ARENA_WORDS": "30000", "ML_PI": "2"}):
+            _reset(ctx)
+            for k, v in knobs.items():
+                ctx.configure("LDPC_AMD_" + k, v)
+            got = ctx.decode(h, sym, era)
+            for a_, b_, what in zip(got, ref, ("out", "sweeps", "residual", "status")):
+                assert np.array_equal(a_, b_), (knobs, what)
+    finally:
+        _reset(ctx)

@@ -52,6 +52,27 @@ def main():
     print(f"{nml} residual frames; {tot / reps / max(nml, 1):.0f} ticks per frame (s_memtime, 100 MHz)")
     for i, name in PHASES.items():
         print(f"   {name:42s} {buf[i] / reps / max(nml, 1):10.0f} ticks per frame  {100.0 * buf[i] / max(tot, 1):5.1f} %")
+    # the solve kernel on the same batch at S = 1024 (wavefront 0 of every workgroup)
+    SOLVE = {32: "solve: task pick-up, table, zeroing", 33: "solve: level 0 (known neighbours from HBM)", 34: "solve: the levels in between",
+             36: "solve: output level + wait"}
+    del cw, src_t, out
+    S = 1024
+    src_t = torch.empty((F, k, S), dtype=torch.uint8, device=dev)
+    ctx.synth_source(11, 0, F, k, S, src_t)
+    cw = ctx.encode(h, src_t).reshape(F, n, S)
+    del src_t
+    out = torch.empty_like(cw)
+    stt = torch.empty(F, dtype=torch.int32, device=dev)
+    for mode in ("1", "2", "0"):
+        ctx.configure("ML_PI", mode)
+        ctx.decode(h, cw, era, out=out, status=stt)
+        L.ldpc_amd_debug_peel_stamps(ctx._h, buf, 1)
+        ctx.decode(h, cw, era, out=out, status=stt)
+        L.ldpc_amd_debug_peel_stamps(ctx._h, buf, 1)
+        stot = sum(buf[i] for i in SOLVE)
+        print(f"ML_PI={mode}, S=1024: solve kernel, {stot / max(nml, 1):.0f} ticks per frame (all slices, wavefront 0)")
+        for i, name in SOLVE.items():
+            print(f"      {name:46s} {buf[i] / max(nml, 1):10.0f} ticks  {100.0 * buf[i] / max(stot, 1):5.1f} %")
     ctx.close()
 
 
