@@ -98,6 +98,7 @@ static const KnobDesc kKnobs[] = {
     LDPC_KNOB_INT("ML_OVERLAP_PRIO", ml_overlap_prio, x >= 0 && x <= 1),
     LDPC_KNOB_INT("ML_OVERLAP", ml_overlap, x >= 0 && x <= 2),
     LDPC_KNOB_INT("ML_PI_IMAX", ml_pi_imax, x >= 0 && x <= 256),
+    LDPC_KNOB_INT("ML_PI_WGS", ml_pi_wgs, x >= 0 && x <= 4096),
     LDPC_KNOB_INT("ML_PI_WAVES", ml_pi_waves, x >= 1 && x <= 4),
     LDPC_KNOB_INT("ML_PI_LDS", ml_pi_lds, x >= 32 && x <= 160),
     LDPC_KNOB_INT("ENC_B", enc_b, x == 128 || x == 256),

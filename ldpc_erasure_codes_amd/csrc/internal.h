@@ -96,6 +96,7 @@ struct Knobs {
                                  // (frames that fail the consistency test are redone exactly: the reference's bytes on ANY input); 2: not
                                  // verified (the reference's bytes when the received symbols are a codeword with erasures); 0: exact only
     int ml_pi_imax = 256;        // ML_PI_IMAX: fast path -- frames that need more inactivations than this go to the exact elimination
+    int ml_pi_wgs = 0;           // ML_PI_WGS: fast path -- at most this many workgroups (0: one per CU's LDS share)
     int ml_pi_waves = 4;         // ML_PI_WAVES: fast path -- at most this many wavefronts (frames) per workgroup
     int ml_pi_lds = 160;         // ML_PI_LDS: KB of LDS per fast-path workgroup (160: one workgroup of up to four frames per CU)
     int ml_overlap_prio = 0;     // ML_OVERLAP_PRIO: 1 = that second stream has the lowest priority (measured slower: 5.67 against 5.45 ms on cfg 3)

@@ -1848,7 +1848,8 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         if (ml_overlap && kn.ml_overlap == 2 && (rc = fork())) return rc;   // =2: the fast path beside the packet kernel too
         if (pi_nw > 0) {
             const int wgs_per_cu = std::max(1, kLdsMax / pi_total);
-            const int pgrid = (int)std::min<int64_t>((nf + pi_nw - 1) / pi_nw, (int64_t)ctx->sm_count * wgs_per_cu);
+            int pgrid = (int)std::min<int64_t>((nf + pi_nw - 1) / pi_nw, (int64_t)ctx->sm_count * wgs_per_cu);
+            if (kn.ml_pi_wgs > 0) pgrid = std::min(pgrid, kn.ml_pi_wgs);
             hipLaunchKernelGGL(ldpc_ml_pi_kernel, dim3(pgrid), dim3(64 * pi_nw), (size_t)pi_total, st, pi);
             LDPC_HIP_TRY(ctx, hipGetLastError());
         }
