@@ -97,6 +97,7 @@ static const KnobDesc kKnobs[] = {
     LDPC_KNOB_INT("ML_PI", ml_pi, x >= 0 && x <= 2),
     LDPC_KNOB_INT("ML_OVERLAP_PRIO", ml_overlap_prio, x >= 0 && x <= 1),
     LDPC_KNOB_INT("ML_OVERLAP", ml_overlap, x >= 0 && x <= 2),
+    LDPC_KNOB_INT("ML_PI_ADAPTIVE", ml_pi_adaptive, x >= 0 && x <= 1),
     LDPC_KNOB_INT("ML_PI_IMAX", ml_pi_imax, x >= 0 && x <= 256),
     LDPC_KNOB_INT("ML_PI_WGS", ml_pi_wgs, x >= 0 && x <= 4096),
     LDPC_KNOB_INT("ML_PI_WAVES", ml_pi_waves, x >= 1 && x <= 4),

@@ -95,6 +95,7 @@ struct Knobs {
     int ml_pi = 1;               // ML_PI: packets -- the fast path (ml_pi.inc: peel on + inactivation) before the exact elimination.  1: verified
                                  // (frames that fail the consistency test are redone exactly: the reference's bytes on ANY input); 2: not
                                  // verified (the reference's bytes when the received symbols are a codeword with erasures); 0: exact only
+    int ml_pi_adaptive = 1;      // ML_PI_ADAPTIVE: skip the fast path's launches for a batch when the previous batch had no residual frame
     int ml_pi_imax = 256;        // ML_PI_IMAX: fast path -- frames that need more inactivations than this go to the exact elimination
     int ml_pi_wgs = 0;           // ML_PI_WGS: fast path -- at most this many workgroups (0: one per CU's LDS share)
     int ml_pi_waves = 4;         // ML_PI_WAVES: fast path -- at most this many wavefronts (frames) per workgroup
@@ -141,6 +142,7 @@ struct ldpc_amd_ctx {
     ldpc_amd::Scratch mllist;   // [1 + nframes] int32: count, frame ids
     ldpc_amd::Scratch biglist;  // [1 + nframes] int32: frames with many steps (scatter tier 2)
     ldpc_amd::Scratch stage_in, stage_er, stage_out, stage_i32;  // host-pointer staging
+    bool ml_head_valid = false;                   // a packet-mode ML stage has copied its demand there at least once
     unsigned long long *ml_head_host = nullptr;   // pinned: arena words the last packet-mode ML stage asked for
     size_t ml_arena_words = 0;  // current size of the solve-schedule arena (64-bit words), grown on demand
     void *pin = nullptr;        // pinned host bounce block of the small-call path
