@@ -459,6 +459,39 @@ def run_cfg2(g, args):
             dts = sharding.max_over_ranks(time.perf_counter() - t1, g.dev)
             s["sustained"] = {"steps": n_sus, "seconds": dts, "ms_per_step": dts / n_sus * 1e3, "frames_per_s": g.world * F * n_sus / dts,
                               "verified": bool(torch.equal(out2, cw))}
+        s["pipelined"] = None
+        if S == args.S and S > 1 and args.sustain_seconds > 0:
+            # Not `value`: the same K steps dealt alternately to TWO contexts, each on its own stream -- independent batches pipeline
+            # (the peel kernel of one batch runs beside the packet kernel of the other: tools/two_stream_probe.py).  A host that
+            # decodes a stream of batches gets this rate; `value` stays the rate of one context, one batch after the other.
+            from ldpc_erasure_codes_amd import api as _api, codes as _codes
+            ctx2 = _api.Context(torch.cuda.current_device())
+            h2 = ctx2.load_builtin_code(1, _codes.DEFAULT_COEF_SEED[1])
+            outb = torch.empty_like(sym)
+            swb, resb, stb = (torch.empty(F, dtype=torch.int32, device=g.dev) for _ in range(3))
+            outa, swa, resa, sta = r["out"], r["sw"], r["res"], r["st"]
+
+            def step(i):
+                if i & 1:
+                    ctx2.decode(h2, sym, era, out=outb, sweeps=swb, residual=resb, status=stb)
+                else:
+                    g.ctx.decode(h, sym, era, out=outa, sweeps=swa, residual=resa, status=sta)
+            kp = max(steps, 20) & ~1
+            for i in range(4):
+                step(i)
+            ctx2.synchronize()
+            g.barrier()
+            t2 = time.perf_counter()
+            for i in range(kp):
+                step(i)
+            ctx2.synchronize()
+            g.barrier()
+            dtp = sharding.max_over_ranks(time.perf_counter() - t2, g.dev)
+            s["pipelined"] = {"contexts": 2, "steps": kp, "ms_per_step": dtp / kp * 1e3, "frames_per_s": g.world * F * kp / dtp,
+                              "verified": bool(torch.equal(outa, cw) and torch.equal(outb, cw)),
+                              "note": "the K steps dealt alternately to two contexts on two streams (independent batches overlap); not `value`"}
+            ctx2.close()
+            del outb
         s["xgmi_probe"] = None
         if S == args.S and g.world > 1 and g.backend == "nccl":
             # not part of `value`: one RCCL all-gather of a 64 MB slice of the decoded output per rank, so that a multi-GPU run
@@ -883,6 +916,8 @@ def main():
         }
         if main_r.get("sustained"):
             line["sustained"] = main_r["sustained"]
+        if main_r.get("pipelined"):
+            line["pipelined_two_contexts"] = main_r["pipelined"]
         if main_r.get("xgmi_probe"):
             line["xgmi_allgather_probe"] = main_r["xgmi_probe"]
         if main_r.get("inplace"):
