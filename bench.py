@@ -549,6 +549,7 @@ def run_cfg3(g, args, S):
                      f"{cw.shape[0]} with E0 < n-k decoded (the rest skipped as in ErasureCodes_NonBinaryLDPCSim.m:216)")
     s["frames_skipped_E0_ge_m"] = int((~keep).sum())
     s["sample"] = pick_samples(r, sym, era, True)
+    s["ml_stage_stats"] = g.ctx.ml_stats()   # of the last step: residual frames, through the fast path, flagged by its test, deferred
     if S > 1:
         # the ML stage's other modes on the same batch (ML_PI knob): 0 = exact elimination only (round 2's
         # path), 2 = fast path without the consistency test (for callers that know their symbols are codewords with erasures).

@@ -221,6 +221,12 @@ const char *ldpc_amd_profile_kernel_name(ldpc_amd_ctx *ctx, int kind);
  * [4] peel LDS bytes per frame, [5] bytes of every row per packet-kernel workgroup (0: no packet kernel), [6] accumulator
  * cap of tier 1, [7] 1 = two tiers.  Diagnostic (tools/tune_s1.py); no reference counterpart. */
 int ldpc_amd_last_plan(ldpc_amd_ctx *ctx, int info[8]);
+/* What the ML stage of the last ldpc_amd_decode_batch (of its last chunk) did, read back from the stage's device counters (the call
+ * waits for the context's stream): stats[0] residual frames handed to the stage, [1] of them solved through the fast path's
+ * schedules (packet mode, csrc/ml_pi.inc; 0 at S = 1), [2] of those flagged by the consistency test and factored again in the
+ * reference's elimination order (received symbols that were not a codeword), [3] frames whose schedule did not fit the arena.
+ * Diagnostic (tests, bench.py); no reference counterpart. */
+int ldpc_amd_ml_stats(ldpc_amd_ctx *ctx, long long stats[4]);
 
 /* ---- diagnostics ----------------------------------------------------------------------------------- */
 /* Device self-test of the GF(256) primitives (packed multiply vs. table) -> 0 when all 65536 products and

@@ -37,7 +37,7 @@ EXPORTS = [
     "ldpc_amd_code_csr", "ldpc_amd_decode_batch", "ldpc_amd_encode_batch", "ldpc_amd_rs_create",
     "ldpc_amd_rs_generator", "ldpc_amd_rs_encode_batch", "ldpc_amd_rs_decode_batch", "ldpc_amd_rs_bad_blocks", "ldpc_amd_synth_source",
     "ldpc_amd_synth_erasures_uniform", "ldpc_amd_synth_erasures_bursty", "ldpc_amd_data_in", "ldpc_amd_ldpc_erasure_decoder", "ldpc_amd_data_out",
-    "ldpc_amd_ldpc_erasure_decoder_perf_tests", "ldpc_amd_fpga_frame_stats", "ldpc_amd_profile_kernel_name", "ldpc_amd_last_plan",
+    "ldpc_amd_ldpc_erasure_decoder_perf_tests", "ldpc_amd_fpga_frame_stats", "ldpc_amd_profile_kernel_name", "ldpc_amd_last_plan", "ldpc_amd_ml_stats",
     "ldpc_amd_fec_header_pack", "ldpc_amd_fec_header_unpack", "ldpc_amd_fec_packetize", "ldpc_amd_fec_rx_create",
     "ldpc_amd_fec_rx_destroy", "ldpc_amd_fec_rx_push", "ldpc_amd_fec_rx_push_many", "ldpc_amd_fec_rx_flush", "ldpc_amd_fec_rx_dropped",
     "ldpc_amd_set_profiling", "ldpc_amd_get_profile", "ldpc_amd_selftest", "ldpc_amd_copy_probe", "ldpc_amd_gf_tables", "ldpc_amd_version",
@@ -119,6 +119,8 @@ def load_library():
     L.ldpc_amd_set_profiling.argtypes = [vp, i32]
     L.ldpc_amd_get_profile.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(i64)]
     L.ldpc_amd_last_plan.argtypes = [vp, C.POINTER(i32)]
+    if hasattr(L, "ldpc_amd_ml_stats"):   # (absent from the older builds tools/ab_lib.py loads)
+        L.ldpc_amd_ml_stats.argtypes = [vp, C.POINTER(C.c_longlong)]
     L.ldpc_amd_profile_kernel_name.argtypes = [vp, i32]
     L.ldpc_amd_profile_kernel_name.restype = C.c_char_p
     L.ldpc_amd_selftest.argtypes = [vp]
@@ -231,6 +233,13 @@ class Context:
         keys = ("frames_per_workgroup", "frames_per_cu", "tables_in_global", "peel_lds_bytes", "peel_lds_per_frame",
                 "packet_bytes_per_workgroup", "tier1_cap", "two_tiers")
         return dict(zip(keys, list(info)))
+
+    def ml_stats(self):
+        """ML stage of the last decode: residual frames, frames solved through the fast path, frames its consistency test flagged
+        (redone exactly), frames whose schedule did not fit the arena.  Synchronises."""
+        st = (C.c_longlong * 4)()
+        self._check(self._L.ldpc_amd_ml_stats(self._h, st), "ml_stats")
+        return dict(zip(("residual_frames", "fast_path_frames", "flagged_frames", "deferred_frames"), [int(x) for x in st]))
 
     def copy_probe(self, src, dst, reps=10):
         """Average device time (ms) of one streaming copy src -> dst (torch CUDA uint8 tensors of equal size)."""

@@ -1169,6 +1169,19 @@ int ldpc_amd_last_plan(ldpc_amd_ctx *ctx, int info[8])
     return LDPC_AMD_OK;
 }
 
+int ldpc_amd_ml_stats(ldpc_amd_ctx *ctx, long long stats[4])
+{
+    if (!ctx || !stats) return LDPC_AMD_EINVAL;
+    stats[0] = stats[1] = stats[2] = stats[3] = 0;
+    if (!ctx->mllist.p) return LDPC_AMD_OK;   // no decode yet
+    LDPC_HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int32_t hdr[32];
+    LDPC_HIP_TRY(ctx, hipMemcpyAsync(hdr, ctx->mllist.p, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
+    LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    stats[0] = hdr[0]; stats[1] = hdr[27]; stats[2] = hdr[24]; stats[3] = hdr[19];   // layout: launch_decode (kernels.hip)
+    return LDPC_AMD_OK;
+}
+
 // ---- diagnostics ---------------------------------------------------------------------------------------
 int ldpc_amd_selftest(ldpc_amd_ctx *ctx)
 {

@@ -1717,8 +1717,9 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         // sit in the free tail of the residual list's header (ints 18..23), which launch_decode zeroes with that header: one
         // memset per call less (a call is launch-bound at S = 1)
         // [1] frames deferred by the launch beside the packet kernel, [5] frame hand-out counter of the fast path (ldpc_ml_pi_kernel)
-        // header ints 24..26: verification failures of the fast path, hand-out counters of the two launches that redo those frames
-        static_assert(kMlHdr >= 27 && 1 + kMlClasses <= 17, "ml_list header: no room for the work counters");
+        // header ints 24..27: verification failures of the fast path, hand-out counters of the two launches that redo those frames,
+        // frames the fast path emitted (read back by ldpc_amd_ml_stats with [0] and [19] = ma.work[1], the deferred frames)
+        static_assert(kMlHdr == 32 && 1 + kMlClasses <= 17, "ml_list header: no room for the work counters");
         ma.work = (int32_t *)ctx->mllist.p + 18;
         ma.work2 = (int32_t *)ctx->mllist.p + 17;   // hand-out counter of the launch that solves the deferred frames (mode 2)
         ma.nfail = (int32_t *)ctx->mllist.p + 24;   // frames whose fast-path solution failed the consistency check (not codewords)
@@ -1813,6 +1814,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             pi.status = d.status; pi.ops = ma.ops; pi.ops_cap = ma.ops_cap; pi.ops_head = ma.ops_head; pi.rec = ma.rec;
             pi.solve_b = solve_b;
             pi.verify = kn.ml_pi == 1 ? 1 : 0;
+            pi.ndone = (int32_t *)ctx->mllist.p + 27;   // frames the fast path emitted (ldpc_amd_ml_stats)
             pi.imax = kn.ml_pi_imax;
             LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(ldpc_ml_pi_kernel)));
         }

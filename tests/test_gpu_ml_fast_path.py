@@ -63,6 +63,9 @@ def test_every_mode_equals_the_oracle_on_codewords(ctx, oracle, code_a):
             assert sw0[f] == o_it and res0[f] == o_res and st0[f] == want, f
             assert np.array_equal(out0[f], o_out), f
         assert np.array_equal(out0[st0 <= 1], cw[st0 <= 1])
+        ms = ctx.ml_stats()   # the default run: most residual frames through the fast path, none flagged (the symbols are codewords)
+        assert ms["residual_frames"] == int((st0 >= 1).sum()) and ms["flagged_frames"] == 0 and ms["deferred_frames"] == 0, ms
+        assert ms["fast_path_frames"] >= 0.8 * ms["residual_frames"] and ms["fast_path_frames"] <= ms["residual_frames"] - int((st0 == 2).sum()), ms
         for pi in ("0", "1", "2"):
             for ov in ("0", "1", "2"):
                 ctx.configure("LDPC_AMD_ML_PI", pi)
@@ -70,6 +73,8 @@ def test_every_mode_equals_the_oracle_on_codewords(ctx, oracle, code_a):
                 got = ctx.decode(h, sym, era)
                 for a_, b_, what in zip(got, ref, ("out", "sweeps", "residual", "status")):
                     assert np.array_equal(a_, b_), (pi, ov, what)
+                ms = ctx.ml_stats()
+                assert (ms["fast_path_frames"] == 0) == (pi == "0") and ms["flagged_frames"] == 0, (pi, ov, ms)
     finally:
         _reset(ctx)
 
@@ -90,6 +95,9 @@ def test_symbols_that_are_not_codewords(ctx, oracle, code_a):
         exact = ctx.decode(h, sym, era)
         ctx.configure("LDPC_AMD_ML_PI", "1")
         verified = ctx.decode(h, sym, era)
+        ms = ctx.ml_stats()   # the corrupted frames the fast path solved are the ones its consistency test must catch
+        n_bad_ml = int((exact[3][F // 2:] == 1).sum())
+        assert ms["flagged_frames"] >= 0.8 * n_bad_ml and ms["flagged_frames"] <= n_bad_ml, (ms, n_bad_ml)
         ctx.configure("LDPC_AMD_ML_PI", "2")
         unverified = ctx.decode(h, sym, era)
         for a_, b_, what in zip(verified, exact, ("out", "sweeps", "residual", "status")):
@@ -138,5 +146,7 @@ def test_code_b_and_a_small_arena(ctx, oracle):
             got = ctx.decode(h, sym, era)
             for a_, b_, what in zip(got, ref, ("out", "sweeps", "residual", "status")):
                 assert np.array_equal(a_, b_), (knobs, what)
+            if "ML_ARENA_WORDS" in knobs:
+                assert ctx.ml_stats()["deferred_frames"] > 0, (knobs, ctx.ml_stats())   # the small arena did overflow
     finally:
         _reset(ctx)
