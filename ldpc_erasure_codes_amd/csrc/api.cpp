@@ -102,6 +102,7 @@ static const KnobDesc kKnobs[] = {
     LDPC_KNOB_INT("ML_PI_WGS", ml_pi_wgs, x >= 0 && x <= 4096),
     LDPC_KNOB_INT("ML_PI_WAVES", ml_pi_waves, x >= 1 && x <= 4),
     LDPC_KNOB_INT("ML_PI_LDS", ml_pi_lds, x >= 32 && x <= 160),
+    LDPC_KNOB_INT("ENC_CLIST", enc_clist, x == 0 || x == 1),
     LDPC_KNOB_INT("ENC_B", enc_b, x == 128 || x == 256),
     LDPC_KNOB_INT("ENC_LIST", enc_list, x == 0 || x == 1),
     {"RS", [](Knobs &k, const char *v) { if (!strcmp(v, "generic")) k.rs_generic = 1; else if (!strcmp(v, "fast")) k.rs_generic = 0; else return false; return true; },
@@ -366,6 +367,26 @@ static int register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_pt
                 enc_src[((size_t)j << cdw_shift) + fillc[j]++] = ((uint32_t)slot_of_row[r] * 128u) | ((uint32_t)hc->coefs[e] << 24);
             }
     }
+    // ... and the lists of the PARITY symbols once more, compact and in schedule order (step s solves symbol k + row(s)): the
+    // encoder's level phase reads them from LDS -- 1023 words + 511 offsets for the (2040,1530) code -- instead of one padded
+    // list per level from global memory behind its own row stores
+    std::vector<uint32_t> enc_lst;
+    std::vector<uint16_t> enc_lst_off(m + 1, 0);
+    if (enc_nlevels > 0) {
+        for (int s_ = 0; s_ < m; s_++) {
+            const int t = (int)(enc_steps[s_] >> 16);
+            enc_lst_off[s_] = (uint16_t)enc_lst.size();
+            for (int i = 0; i < (1 << cdw_shift); i++) {
+                const uint32_t w = enc_src[((size_t)t << cdw_shift) + i];
+                if (w == 0xFFFFFFFFu) break;
+                enc_lst.push_back(w);
+            }
+        }
+        enc_lst_off[m] = (uint16_t)enc_lst.size();
+        if (enc_lst.size() >= 0xFFFFu) { enc_lst.clear(); }   // (offsets are 16-bit: such a code keeps the global lists)
+    }
+    const int enc_lst_n = (int)enc_lst.size();
+    if (enc_lst.empty()) enc_lst.assign(1, 0xFFFFFFFFu);
     // encoder: source rows in the order of their column degree (every check is a step of the static schedule, so a row's
     // degree IS the number of accumulators it feeds): the row pieces a wavefront handles at once then take the same number
     // of edge turns
@@ -382,12 +403,14 @@ static int register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_pt
     d.n = n; d.k = k; d.m = m; d.nnz = hc->nnz; d.maxdeg = maxdeg; d.degpad = degpad; d.mpad = mpad;
     d.maxcoldeg = maxcoldeg; d.cdw_shift = cdw_shift;
     d.enc_nlevels = enc_nlevels;
+    d.enc_lst_n = enc_lst_n;
     int rc;
     if ((rc = upload(ctx, hc, hc->row_ptr, &d.row_ptr)) || (rc = upload(ctx, hc, edges, &d.edges)) ||
         (rc = upload(ctx, hc, ell_col, &d.ell_col)) || (rc = upload(ctx, hc, ell_logc, &d.ell_logc)) ||
         (rc = upload(ctx, hc, ell_coef, &d.ell_coef)) || (rc = upload(ctx, hc, ell_pk, &d.ell_pk)) || (rc = upload(ctx, hc, cell, &d.cell)) ||
         (rc = upload(ctx, hc, enc_src, &d.enc_src)) || (rc = upload(ctx, hc, enc_order, &d.enc_order)) || (rc = upload(ctx, hc, enc_invc, &d.enc_invc)) ||
-        (rc = upload(ctx, hc, enc_steps, &d.enc_steps)) || (rc = upload(ctx, hc, enc_lvlend, &d.enc_lvlend))) {
+        (rc = upload(ctx, hc, enc_steps, &d.enc_steps)) || (rc = upload(ctx, hc, enc_lvlend, &d.enc_lvlend)) ||
+        (rc = upload(ctx, hc, enc_lst, &d.enc_lst)) || (rc = upload(ctx, hc, enc_lst_off, &d.enc_lst_off))) {
         free_code(hc);
         return rc;
     }

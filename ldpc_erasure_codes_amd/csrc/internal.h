@@ -55,6 +55,9 @@ struct DevCode {
     int enc_nlevels;
     const uint32_t *enc_src;     // [n][1 << cdw_shift] static symbol -> (slot * 128 | coef << 24) lists of the encoder (LDS offset of the slot's 128-byte piece)
     const uint16_t *enc_order;   // [k] source symbols ordered by the number of checks they feed (most first; index order within)
+    const uint32_t *enc_lst;     // [enc_lst_n] the enc_src lists of the parity symbols, compact, in schedule order (level phase of the encoder)
+    const uint16_t *enc_lst_off; // [m + 1] step -> first word of its list
+    int enc_lst_n;               // 0: not available (more than 65534 words)
 };
 
 struct HostCode {
@@ -103,6 +106,7 @@ struct Knobs {
     int ml_overlap_prio = 0;     // ML_OVERLAP_PRIO: 1 = that second stream has the lowest priority (measured slower: 5.67 against 5.45 ms on cfg 3)
     int ml_overlap = 2;          // ML_OVERLAP: packets -- the factorisation runs on a second stream beside the packet kernel; 0 = behind it
     int ml_pack = 2;             // ML_PACK: ML-kernel workgroups per CU (1, 2, 3, 4): 1024 / P threads and 160 KB / P of LDS each
+    int enc_clist = 1;           // ENC_CLIST: encoder -- the level phase reads the parity symbols' lists from LDS (compact copy); 0: from global memory
     int enc_b = 128;             // ENC_B: encoder piece size (128: two workgroups per CU; 256: the decoder's plan)
     int enc_list = 0;            // ENC_LIST: encoder streams the source rows in the order of their column degree
     int rs_generic = 0;          // RS=generic: RS decode always through the generic LDS kernel

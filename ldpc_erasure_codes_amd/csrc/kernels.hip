@@ -606,6 +606,7 @@ struct ScatterArgs {
     int lds_acc, lds_tgt, lds_invc, lds_lvlend, lds_rowctr, lds_mt, lds_soc, lds_chk;
     int lds_soc_bytes;        // size of the row-kind / row-list region
     int enc_list;             // encode: stream the source rows in DevCode::enc_order
+    int enc_clist;            // encode: the level phase reads DevCode::enc_lst from LDS (copied over the dead row tables at lds_soc)
     int dbg;                  // diagnostic build only (-DLDPC_AMD_MLDBG): 32768 = tier 1 also takes the frames with more than tcap steps,
                               // cut off at tcap steps (WRONG bytes: prices the first pass of a level-split tier 2)
 };
@@ -1114,17 +1115,38 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     //      lists in LDS the loop contains no global load, so nothing in it waits on the memory counter (a load would
     //      wait for the row stores issued before it, once per level); the other one reads the lists from global memory
     //      and requests a wave's first list of the next level before the barrier.
+    // (Encoder: the lists of the parity symbols, compact -- DevCode::enc_lst -- are copied over the row tables the streaming phase
+    // is done with; round 3: its level phase was 59 % of a workgroup's time with one global list load per level, tools/stamp_encode.py.)
+    const uint32_t *clist = reinterpret_cast<const uint32_t *>(smem + a.lds_soc);
+    const uint16_t *coff = reinterpret_cast<const uint16_t *>(smem + a.lds_soc + 4 * cd.enc_lst_n);
+    if (a.static_sched && a.enc_clist) {
+        uint32_t *cw_ = reinterpret_cast<uint32_t *>(smem + a.lds_soc);
+        uint16_t *co_ = reinterpret_cast<uint16_t *>(smem + a.lds_soc + 4 * cd.enc_lst_n);
+        for (int i = tid; i < cd.enc_lst_n; i += nthr) cw_[i] = cd.enc_lst[i];
+        for (int i = tid; i <= nsteps; i += nthr) co_[i] = cd.enc_lst_off[i];
+        __syncthreads();
+    }
     auto phase_b = [&](auto lds_tag) {
-        constexpr bool LL = decltype(lds_tag)::value;
+        constexpr int MODE = decltype(lds_tag)::value;   // 0: lists from global memory, 1: padded lists in LDS, 2: compact lists in LDS
+        constexpr bool LL = MODE != 0;
         auto load_list = [&](int s, int s1, uint32_t (&ew)[KQ]) {
 #pragma unroll
             for (int q = 0; q < KQ; q++) ew[q] = 0xFFFFFFFFu;
             if (s < s1) {
+                if (MODE == 2) {
+                    const uint32_t o0 = coff[s], o1 = coff[s + 1];
+#pragma unroll
+                    for (int q = 0; q < KQ; q++) {
+                        const uint32_t idx = o0 + (uint32_t)(gl + q * LPR);
+                        if (idx < o1) ew[q] = clist[idx];
+                    }
+                    return;
+                }
                 const int t = tgt[s];
 #pragma unroll
                 for (int q = 0; q < KQ; q++) {
                     const int idx = gl + q * LPR;
-                    if (idx < cdw) ew[q] = LL ? slist[s * cdw + idx] : spad[((uint32_t)t << cd.cdw_shift) + (uint32_t)idx];
+                    if (idx < cdw) ew[q] = MODE == 1 ? slist[s * cdw + idx] : spad[((uint32_t)t << cd.cdw_shift) + (uint32_t)idx];
                 }
             }
         };
@@ -1156,8 +1178,9 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
             __syncthreads();
         }
     };
-    if (lds_lists) phase_b(std::true_type{});
-    else phase_b(std::false_type{});
+    if (a.static_sched && a.enc_clist) phase_b(std::integral_constant<int, 2>{});
+    else if (lds_lists) phase_b(std::integral_constant<int, 1>{});
+    else phase_b(std::integral_constant<int, 0>{});
     LDPC_STAMP(15);  // scatter: level phase
 }
 
@@ -2053,9 +2076,21 @@ int launch_encode(ldpc_amd_ctx *ctx, const DevCode &cd, int S, int64_t nframes, 
                     plan = q;
                 }
             }
+            // the compact lists of the parity symbols for the level phase: over the row tables (dead by then), which end the layout --
+            // the allocation grows by what they need beyond those tables when that still fits
+            int enc_clist = 0;
+            if (kn.enc_clist && cd.enc_lst_n > 0) {
+                const int need = 4 * cd.enc_lst_n + align_up(2 * (cd.m + 1), 16);
+                const int soc_off = 8192 + align_up(cd.m * 16 * plan.lpr, 16) + plan.o_soc;
+                const int limit = (plan.two_tier && plan.lpr == 8) ? kLdsMax / 2 : kLdsMax;
+                if (soc_off + need <= limit) {
+                    enc_clist = 1;
+                    plan.lds1 = plan.lds2 = std::max(plan.lds1, soc_off + need);
+                }
+            }
             ScatterArgs sa{};
             sa.code = cd; sa.S = S; sa.nslices = plan.nslices; sa.nframes = nframes; sa.sym = src; sa.erased = nullptr; sa.out = cw;
-            sa.in_rows = cd.k; sa.static_sched = 1;
+            sa.in_rows = cd.k; sa.static_sched = 1; sa.enc_clist = enc_clist;
             sa.enc_list = kn.enc_list;   // measured slower (4.62 vs 4.14 ms): off unless asked for
             return launch_scatter(ctx, plan, sa, nullptr);
         }
