@@ -51,6 +51,22 @@ def main():
         print(f"decoder, uniform 10 %: {tot / F:.0f} cycles per frame")
         for i, name in PHASES.items():
             print(f"   {name:48s} {100.0 * buf[i] / max(tot, 1):5.1f} %")
+        if code_ind == 1:   # the bursty channel of cfg 3: 79 % of the frames in tier 2 (one workgroup per CU)
+            import numpy as np
+            from ldpc_erasure_codes_amd import synth
+            era_np = synth.erasures_bursty(31, 0, 2 * F, n, 0.13, 0.8, 10.0)
+            era_np = np.ascontiguousarray(era_np[era_np.sum(axis=1) < n - k][:F])
+            era = torch.from_numpy(era_np).to(dev)
+            ctx.configure("LDPC_AMD_ML_PI", "0"); ctx.configure("LDPC_AMD_ML_OVERLAP", "0")
+            ctx.decode(h, cw, era, out=out)
+            L.ldpc_amd_debug_peel_stamps(ctx._h, buf, 1)
+            ctx.decode(h, cw, era, out=out)
+            L.ldpc_amd_debug_peel_stamps(ctx._h, buf, 1)
+            ctx.configure("LDPC_AMD_ML_PI", None); ctx.configure("LDPC_AMD_ML_OVERLAP", None)
+            tot = sum(buf[i] for i in PHASES)
+            print(f"decoder, bursty channel of cfg 3 (both tiers): {tot / F:.0f} cycles per frame")
+            for i, name in PHASES.items():
+                print(f"   {name:48s} {100.0 * buf[i] / max(tot, 1):5.1f} %")
         del src_t, cw, era, out
         torch.cuda.empty_cache()
     ctx.close()
