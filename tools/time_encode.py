@@ -13,15 +13,17 @@ from ldpc_erasure_codes_amd import api  # noqa: E402
 
 ctx = api.Context(0)
 ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-h = ctx.load_builtin_code(1, 2040)
+CODE = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+h = ctx.load_builtin_code(CODE, {1: 2040, 3: 4080}[CODE])
 n, k, _ = ctx.code_info(h)
-F, S = 4096, 1024
+F, S = (4096 if CODE == 1 else 2048), 1024
 src = torch.empty((F, k, S), dtype=torch.uint8, device="cuda")
 ctx.synth_source(1, 0, F, k, S, src)
 variants = {"gather": {"LDPC_AMD_APPLY": "gather"}, "scatter B=256 (1 WG/CU)": {"LDPC_AMD_ENC_B": "256"}, "scatter B=128 (2 WG/CU)": {},
             "B=128, rows by column degree": {"LDPC_AMD_ENC_LIST": "1"}, "B=128 dyn0": {"LDPC_AMD_SCATTER_DYN": "0"},
             "B=128 R=4": {"LDPC_AMD_SCATTER_R": "4"}, "B=128 list mode": {"LDPC_AMD_SCATTER_DYN": "2"},
-            "B=128 no XCD placement": {"LDPC_AMD_SCATTER_XCD": "0"}}
+            "B=128 no XCD placement": {"LDPC_AMD_SCATTER_XCD": "0"},
+            "B=128, level lists from global memory": {"LDPC_AMD_ENC_CLIST": "0"}}
 times = {v: [] for v in variants}
 ref = None
 cw = torch.empty((F, n, S), dtype=torch.uint8, device="cuda")
