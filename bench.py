@@ -492,6 +492,22 @@ def run_cfg2(g, args):
                               "note": "the K steps dealt alternately to two contexts on two streams (independent batches overlap); not `value`"}
             ctx2.close()
             del outb
+        s["encoder"] = None
+        if S == args.S and S > 1 and args.sustain_seconds > 0:
+            # SURVEY 8(f) row 1, the step before the path: the systematic encoder on the same batch (k S bytes in, n S bytes out per frame)
+            srcb = cw[:, :k, :].contiguous()
+            enc = torch.empty_like(cw)
+            g.ctx.encode(h, srcb, out=enc)
+            g.barrier()
+            t3 = time.perf_counter()
+            for _ in range(5):
+                g.ctx.encode(h, srcb, out=enc)
+            g.barrier()
+            dte = sharding.max_over_ranks(time.perf_counter() - t3, g.dev) / 5
+            eb = float(F) * (k + n) * S
+            s["encoder"] = {"ms_per_batch": dte * 1e3, "frames_per_s": g.world * F / dte, "alg_bytes_per_batch": eb,
+                            "GBps": eb / dte / 1e9, "of_hbm_peak": eb / dte / 1e9 / HBM_PEAK_GBPS, "verified": bool(torch.equal(enc, cw))}
+            del srcb, enc
         s["xgmi_probe"] = None
         if S == args.S and g.world > 1 and g.backend == "nccl":
             # not part of `value`: one RCCL all-gather of a 64 MB slice of the decoded output per rank, so that a multi-GPU run
@@ -919,6 +935,8 @@ def main():
             line["sustained"] = main_r["sustained"]
         if main_r.get("pipelined"):
             line["pipelined_two_contexts"] = main_r["pipelined"]
+        if main_r.get("encoder"):
+            line["encoder"] = main_r["encoder"]
         if main_r.get("xgmi_probe"):
             line["xgmi_allgather_probe"] = main_r["xgmi_probe"]
         if main_r.get("inplace"):
