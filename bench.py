@@ -438,8 +438,12 @@ def run_cfg2(g, args):
         if S >= 16:
             # the copy rate this box reaches (same buffers, same streaming loads/stores), quoted next to the
             # nominal HBM peak; bytes moved = read + write
-            copy_ms = g.ctx.copy_probe(sym, r["out"], reps=5)
-            copy_gbps = 2.0 * sym.numel() / (copy_ms * 1e-3) / 1e9
+            # best single launch over 20 repetitions of five launch shapes, at two sizes (the whole batch and a quarter of it)
+            copy_gbps = 0.0
+            for nb in (sym.numel(), (sym.numel() // 4) & ~4095):
+                if nb >= 4096:
+                    copy_ms = g.ctx.copy_probe(sym, r["out"], reps=20, nbytes=nb)
+                    copy_gbps = max(copy_gbps, 2.0 * nb / (copy_ms * 1e-3) / 1e9)
         traffic, tsrc = pmc_traffic(r["names"][kind]) if F == 4096 else (None, None)
         s["roofline"] = {"bound": "hbm", "kernel": r["names"][kind], "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": tsrc,
@@ -664,7 +668,22 @@ def run_cfg4_packets(g, args, S=1024):
     s["plan"] = ctx.last_plan()
     s["S"] = S
     s["sample"] = pick_samples(r, sym, era, False)
-    del cw, sym, r
+    del sym, r
+    torch.cuda.empty_cache()
+    # the (4080,3060) encoder on the same frames: k S bytes in, n S bytes out per frame
+    srcb = cw[:, :k, :].contiguous()
+    enc = torch.empty_like(cw)
+    ctx.encode(h, srcb, out=enc)
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    for _ in range(5):
+        ctx.encode(h, srcb, out=enc)
+    torch.cuda.synchronize()
+    dte = (time.perf_counter() - t3) / 5
+    eb = float(F) * (k + n) * S
+    enc_leg = {"ms_per_batch": dte * 1e3, "frames_per_s": F / dte, "alg_bytes_per_batch": eb, "GBps": eb / dte / 1e9,
+               "of_hbm_peak": eb / dte / 1e9 / HBM_PEAK_GBPS, "verified": bool(torch.equal(enc, cw))}
+    del cw, srcb, enc
     torch.cuda.empty_cache()
 
     # ---- RS(255,223), S-byte packets, on the same erasure patterns (block i = symbols 255 i ... 255 i + 254)
@@ -707,7 +726,7 @@ def run_cfg4_packets(g, args, S=1024):
     s_rs["sample"] = (idx[:2].cpu().numpy().astype(np.uint16), val[:2].cpu().numpy(), msg[:2].cpu().numpy())
     del era, idx, val, order, msg, rsrc
     torch.cuda.empty_cache()
-    return {"ldpc": s, "rs": s_rs}
+    return {"ldpc": s, "rs": s_rs, "encoder": enc_leg}
 
 
 def run_cfg5(g, args, total, gather, S=1):
@@ -975,7 +994,135 @@ def main():
         }
         if head.get("cpu_baseline"):
             line["cpu_baseline"] = head["cpu_baseline"]
-    print(json.dumps(line))
+    # ---- ONE line on stdout, short enough for the driver's tail: the required keys, `roofline`, `cpu_baseline`
+    # and a flat per-config `summary` LAST; everything else (per-kernel name maps, workload prose, histograms, the ML stage's other
+    # modes, the CPU legs' sample texts) goes to the detail file written by this same run.
+    detail_rel = os.path.join("profiles", "round4_bench_detail.json")
+    written = []
+    for dpath in (os.path.join(ROOT, detail_rel), os.path.join(ROOT, "gpurun_out", "round4_bench_detail.json")):
+        try:
+            if os.path.isdir(os.path.dirname(dpath)):
+                with open(dpath, "w") as fh:
+                    json.dump(line, fh, indent=1)
+                written.append(os.path.relpath(dpath, ROOT))
+        except OSError as e:
+            print(f"bench.py: could not write {dpath}: {e}", file=sys.stderr)
+    print(json.dumps(compact_line(line, written[0] if written else None), separators=(",", ":")))
+
+
+def _r(x, sig=4):
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    try:
+        return float(f"{float(x):.{sig}g}")
+    except (TypeError, ValueError):
+        return x
+
+
+SHORT_KERNEL = (("ldpc_scatter_big_kernel", "scatter_big"), ("ldpc_scatter_kernel", "scatter"), ("ldpc_peel_kernel", "peel"),
+                ("ldpc_ml_solve_kernel", "ml_solve"), ("ldpc_ml_kernel", "ml"), ("rs_decode_packets_kernel", "rs_packets"),
+                ("rs_decode_s1_kernel", "rs_s1"))
+
+
+def _short(name):
+    if not name:
+        return name
+    for long, short in SHORT_KERNEL:
+        if name.startswith(long):
+            return short + name[len(long):].replace(" ", "")
+    return name.replace(" ", "")
+
+
+def _cfg_summary(e):
+    """Flat per-config record: ms per step, frames/s, roofline fraction, dominant kernel + its ms, verified, ML stage."""
+    if not e:
+        return None
+    o = {"ms": _r(e.get("ms_per_step", e.get("decode_ms_per_step"))), "fps": _r(e.get("frames_per_s", e.get("blocks_per_s"))),
+         "frac": _r(e.get("roofline_frac"), 3), "ok": e.get("verified")}
+    km = e.get("kernel_ms") or {}
+    if km:
+        dom = max(km, key=lambda kk: km[kk])
+        o["k"] = _short((e.get("kernels") or {}).get(dom)) or dom
+        o["kms"] = {kk: _r(v, 3) for kk, v in km.items() if v >= 0.02}
+    if e.get("roofline"):
+        o["kfrac"] = _r(e["roofline"]["frac"], 3)
+    if e.get("ml_trigger_rate"):
+        o["ml_rate"] = _r(e["ml_trigger_rate"], 3)
+        o["rankdef"] = _r(e.get("rank_deficient_rate"), 2)
+    if e.get("ml_stage_stats"):
+        st = e["ml_stage_stats"]
+        o["ml"] = [st["residual_frames"], st["fast_path_frames"], st["flagged_frames"], st["deferred_frames"]]
+    if e.get("gather_ms") is not None:
+        o["gather_ms"] = _r(e["gather_ms"], 3)
+    cb = e.get("cpu_baseline")
+    if cb:
+        o["cpu"] = [_r(cb.get("single_thread"), 3), _r(cb.get("value"), 3)]
+    return o
+
+
+def compact_line(line, detail_file):
+    keep = ("metric", "value", "unit", "recovered_GBps", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "verified_bit_exact", "ml_trigger_rate")
+    out = {kk: line[kk] for kk in keep if kk in line}
+    out["metric"] = out["metric"].split(" (cfg 2:")[0]
+    out["value"] = _r(out["value"], 7)
+    out["ms_per_step"] = _r(out["ms_per_step"], 5)
+    if "recovered_GBps" in out:
+        out["recovered_GBps"] = _r(out["recovered_GBps"], 5)
+    if isinstance(out.get("config"), dict) and "workload" in out["config"]:
+        out["config"] = dict(out["config"], workload=out["config"]["workload"][:160])
+    if line.get("kernel_ms"):
+        out["kernel_ms"] = {kk: _r(v, 4) for kk, v in line["kernel_ms"].items()}
+    if line.get("roofline"):
+        rf = line["roofline"]
+        out["roofline"] = {kk: (_r(rf[kk], 5) if kk not in ("kernel", "bound", "unit", "traffic_source") else rf[kk]) for kk in
+                           ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "alg_bytes_per_launch",
+                            "avg_launch_ms", "copy_kernel_GBps", "frac_of_copy") if kk in rf}
+        if out["roofline"].get("traffic_source"):
+            out["roofline"]["traffic_source"] = out["roofline"]["traffic_source"].split(" (")[0] + " (replayed)"
+    if line.get("cpu_baseline"):
+        cb = line["cpu_baseline"]
+        out["cpu_baseline"] = {"value": _r(cb.get("value"), 5), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                               "sample": (cb.get("sample") or "")[:150], "single_thread": _r(cb.get("single_thread"), 4),
+                               "cpu_model": cb.get("cpu_model")}
+        out["gpu_over_cpu"] = _r(line.get("gpu_over_cpu"), 4)
+    out["detail_file"] = detail_file
+    sm = {}
+    cfgs = line.get("configs") or {}
+    for name in ("sustained", "pipelined_two_contexts"):
+        if line.get(name):
+            sm[name] = {"ms": _r(line[name]["ms_per_step"]), "fps": _r(line[name]["frames_per_s"]), "ok": line[name].get("verified")}
+    if line.get("inplace_extension"):
+        ip = line["inplace_extension"]
+        sm["inplace"] = {"ms": _r(ip["ms_per_step"]), "fps": _r(ip["frames_per_s"]), "ok": ip["verified_bit_exact"]}
+    for name in ("cfg5_S64_outputs", "cfg5_one_eighth", "cfg5"):
+        if cfgs.get(name):
+            sm[name] = _cfg_summary(cfgs[name])
+    for name in ("cfg4", "cfg4_S1024"):
+        if cfgs.get(name):
+            sm[name + "_rs"] = _cfg_summary(cfgs[name].get("rs"))
+            sm[name + "_ldpc"] = _cfg_summary(cfgs[name].get("ldpc"))
+    for name, e in sorted(cfgs.items()):
+        if name.endswith("_error"):
+            sm[name] = str(e)[:120]
+    if line.get("encoder"):
+        en = line["encoder"]
+        sm["encoder_2040"] = {"ms": _r(en["ms_per_batch"]), "frac": _r(en["of_hbm_peak"], 3), "ok": en["verified"]}
+    if (cfgs.get("cfg4_S1024") or {}).get("encoder"):
+        en = cfgs["cfg4_S1024"]["encoder"]
+        sm["encoder_4080"] = {"ms": _r(en["ms_per_batch"]), "frac": _r(en["of_hbm_peak"], 3), "ok": en["verified"]}
+    if line.get("s1"):
+        s1 = line["s1"]
+        sm["cfg2_S1"] = {"ms": _r(s1["ms_per_step"]), "fps": _r(s1["value"]), "frac": _r(s1["roofline"]["frac"], 3),
+                         "ok": s1["verified_bit_exact"]}
+        if s1.get("cpu_baseline"):
+            sm["cfg2_S1"]["cpu"] = [_r(s1["cpu_baseline"].get("single_thread"), 3), _r(s1["cpu_baseline"].get("value"), 3)]
+    for name in ("cfg3_S1", "cfg3_S1024"):     # the hybrid-ML config LAST: it must survive any tail cut
+        if cfgs.get(name):
+            sm[name] = _cfg_summary(cfgs[name])
+    if sm:
+        out["summary"] = sm
+    return out
 
 
 if __name__ == "__main__":

@@ -65,6 +65,8 @@ void ldpc_amd_cleanup(ldpc_amd_ctx *ctx);
 const char *ldpc_amd_last_error(const ldpc_amd_ctx *ctx);
 /* Use a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own. */
 int ldpc_amd_set_stream(ldpc_amd_ctx *ctx, void *hip_stream);
+/* Waits for the context's stream.  Also the point where a violated internal assumption reported by a kernel of an earlier
+ * asynchronous call (e.g. dynamic LDS not at LDS address 0) comes back as LDPC_AMD_EHIP instead of silently wrong bytes. */
 int ldpc_amd_synchronize(ldpc_amd_ctx *ctx);
 /* Tuning / diagnostic knobs of this context (the table of DESIGN.md's appendix: "SCATTER_B", "ML_SOLVE", "HOST_PIPELINE", ... with
  * or without the LDPC_AMD_ prefix, case-insensitive; value NULL or "" restores the shipped default).  The environment variables
@@ -225,6 +227,10 @@ int ldpc_amd_last_plan(ldpc_amd_ctx *ctx, int info[8]);
  * waits for the context's stream): stats[0] residual frames handed to the stage, [1] of them solved through the fast path's
  * schedules (packet mode, csrc/ml_pi.inc; 0 at S = 1), [2] of those flagged by the consistency test and factored again in the
  * reference's elimination order (received symbols that were not a codeword), [3] frames whose schedule did not fit the arena.
+ * One-batch lag of the adaptive skip (knob ML_PI_ADAPTIVE, default on): a context whose previous packet batch had NO residual frame
+ * skips the fast path's launches for the next batch, so the first residual-heavy batch after a clean one reports [1] = 0 (all its
+ * frames are factored exactly -- same bytes, slower) and the batch after that has the fast path again.  "Previous" means the last
+ * batch whose counters had reached the host when this one was launched (an un-awaited copy), so the lag is one batch or more.
  * Diagnostic (tests, bench.py); no reference counterpart. */
 int ldpc_amd_ml_stats(ldpc_amd_ctx *ctx, long long stats[4]);
 
@@ -233,7 +239,8 @@ int ldpc_amd_ml_stats(ldpc_amd_ctx *ctx, long long stats[4]);
  * 255 inverses agree with the host tables. */
 int ldpc_amd_selftest(ldpc_amd_ctx *ctx);
 /* Device-to-device copy of `bytes` (16-byte multiple, device pointers) with the streaming loads/stores of the packet
- * kernel, `reps` times after one warm-up; *ms_per_copy = average device time.  The measured copy rate of the box is what
+ * kernel: `reps` single launches of each of five launch shapes after a warm-up; *ms_per_copy = the BEST single launch (the
+ * figure is quoted as what a linear read + write copy reaches on this box).  The measured copy rate of the box is what
  * SURVEY.md 8(d) asks to be quoted next to the nominal HBM peak; no reference counterpart. */
 int ldpc_amd_copy_probe(ldpc_amd_ctx *ctx, const void *src, void *dst, uint64_t bytes, int reps, double *ms_per_copy);
 /* Host copy of the GF tables the kernels use: mult[256*256], inv[256] (inv[0] = 0), either may be NULL. */

@@ -241,10 +241,11 @@ class Context:
         self._check(self._L.ldpc_amd_ml_stats(self._h, st), "ml_stats")
         return dict(zip(("residual_frames", "fast_path_frames", "flagged_frames", "deferred_frames"), [int(x) for x in st]))
 
-    def copy_probe(self, src, dst, reps=10):
-        """Average device time (ms) of one streaming copy src -> dst (torch CUDA uint8 tensors of equal size)."""
+    def copy_probe(self, src, dst, reps=10, nbytes=None):
+        """Best single-launch device time (ms) of a streaming copy src -> dst (torch CUDA uint8 tensors of equal size;
+        nbytes: copy only that many leading bytes), over `reps` launches of each of the probe's launch shapes."""
         ms = C.c_double(0.0)
-        nbytes = src.numel() * src.element_size()
+        nbytes = min(nbytes or (1 << 62), src.numel() * src.element_size())
         self._check(self._L.ldpc_amd_copy_probe(self._h, src.data_ptr(), dst.data_ptr(), nbytes & ~15, reps, C.byref(ms)), "copy_probe")
         return ms.value
 

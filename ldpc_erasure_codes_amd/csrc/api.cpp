@@ -91,7 +91,7 @@ static const KnobDesc kKnobs[] = {
     LDPC_KNOB_INT("ML_SOLVE", ml_solve, x >= 0 && x <= 2),
     LDPC_KNOB_INT("ML_DBG", ml_dbg, x >= 0),
     LDPC_KNOB_INT("ML_SOLVE_B", ml_solve_b, x == 16 || x == 32 || x == 64 || x == 128),
-    LDPC_KNOB_INT("ML_ARENA_WORDS", ml_arena_words, x == 0 || x >= 1024),
+    LDPC_KNOB_INT("ML_ARENA_WORDS", ml_arena_words, x == 0 || (x >= 1024 && x <= (1ll << 27))),
     LDPC_KNOB_INT("ML_THREADS", ml_threads, x == 0 || (x >= 256 && x <= 1024 && (x % 64) == 0)),
     LDPC_KNOB_INT("ML_PACK", ml_pack, x >= 1 && x <= 4),
     LDPC_KNOB_INT("ML_PI", ml_pi, x >= 0 && x <= 2),
@@ -126,14 +126,20 @@ int knob_set(Knobs &k, const char *key, const char *value)
     return -1;
 }
 
-void knobs_from_env(Knobs &k)
+bool knobs_from_env(Knobs &k, std::string *rejected)
 {
     char name[64];
     for (const KnobDesc &d : kKnobs) {
         snprintf(name, sizeof(name), "LDPC_AMD_%s", d.name);
         const char *v = getenv(name);   // the ONLY getenv of the library: once per context, inside ldpc_amd_init
-        if (v && *v) (void)d.set(k, v); // a malformed value leaves the default, like the per-call parsing it replaces
+        if (v && *v && !d.set(k, v)) {
+            // the same rule as ldpc_amd_configure: a value the knob does not take is an error, never a silently kept default
+            // (an A/B script with a typo would otherwise measure the default under the wrong label)
+            if (rejected) *rejected = std::string(name) + "=" + v;
+            return false;
+        }
     }
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -151,6 +157,15 @@ int set_error(ldpc_amd_ctx *ctx, int code, const char *fmt, ...)
     if (ctx) ctx->err = buf;
     else g_init_error = buf;
     return code;
+}
+
+int check_device_error(ldpc_amd_ctx *ctx)
+{
+    if (!ctx->dev_err_host) return LDPC_AMD_OK;
+    const int bits = __atomic_exchange_n(ctx->dev_err_host, 0, __ATOMIC_ACQ_REL);
+    if (!bits) return LDPC_AMD_OK;
+    return set_error(ctx, LDPC_AMD_EHIP, "a kernel reported a violated internal assumption (bits 0x%x: 1 = dynamic LDS not at LDS address 0); "
+                     "the frames it handled were left undecoded", bits);
 }
 
 int scratch_reserve(ldpc_amd_ctx *ctx, Scratch &s, size_t bytes)
@@ -608,12 +623,19 @@ int ldpc_amd_init(int device_ordinal, ldpc_amd_ctx **out)
     if (!ctx) return set_error(nullptr, LDPC_AMD_ENOMEM, "out of host memory");
     ctx->device = device_ordinal;
     ctx->sm_count = prop.multiProcessorCount;
-    knobs_from_env(ctx->knobs);   // the environment is looked at here and nowhere else
+    std::string bad_knob;
+    if (!knobs_from_env(ctx->knobs, &bad_knob)) {   // the environment is looked at here and nowhere else
+        delete ctx;
+        return set_error(nullptr, LDPC_AMD_EINVAL, "ldpc_amd_init: environment knob rejected (unparsable or out of range): %s", bad_knob.c_str());
+    }
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) {
         delete ctx;
         return set_error(nullptr, LDPC_AMD_EHIP, "hipStreamCreate: %s", hipGetErrorString(e));
     }
     ctx->own_stream = true;
+    // device-visible pinned word the kernels report violated assumptions through (checked after every synchronisation)
+    if (hipHostMalloc((void **)&ctx->dev_err_host, 64, hipHostMallocMapped | hipHostMallocPortable) == hipSuccess) *ctx->dev_err_host = 0;
+    else ctx->dev_err_host = nullptr;
     if ((e = upload_constants(ctx->stream)) != hipSuccess) {
         (void)hipStreamDestroy(ctx->stream);
         delete ctx;
@@ -650,6 +672,7 @@ void ldpc_amd_cleanup(ldpc_amd_ctx *ctx)
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     if (ctx->ml_head_host) (void)hipHostFree(ctx->ml_head_host);
+    if (ctx->dev_err_host) (void)hipHostFree(ctx->dev_err_host);
     delete ctx;
 }
 
@@ -681,7 +704,7 @@ int ldpc_amd_synchronize(ldpc_amd_ctx *ctx)
 {
     if (!ctx) return LDPC_AMD_EINVAL;
     LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return LDPC_AMD_OK;
+    return check_device_error(ctx);
 }
 
 int ldpc_amd_code_params(int code_ind, int params[6])
@@ -781,6 +804,7 @@ int ldpc_amd_decode_batch(ldpc_amd_ctx *ctx, int code, int S, int64_t nframes, c
         if ((rc = launch_decode(ctx, d))) return rc;
         LDPC_HIP_TRY(ctx, hipMemcpyAsync(hp + o_out, dp + o_out, total - o_out, hipMemcpyDeviceToHost, ctx->stream));
         LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if ((rc = check_device_error(ctx))) return rc;
         memcpy(out, hp + o_out, fbytes * nframes);
         const int32_t *h32 = (const int32_t *)(hp + o_i32);
         if (sweeps) memcpy(sweeps, h32, sizeof(int32_t) * nframes);
@@ -802,7 +826,7 @@ int ldpc_amd_decode_batch(ldpc_amd_ctx *ctx, int code, int S, int64_t nframes, c
     if (residual) LDPC_HIP_TRY(ctx, hipMemcpyAsync(residual, d.residual, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, ctx->stream));
     if (status) LDPC_HIP_TRY(ctx, hipMemcpyAsync(status, d.status, sizeof(int32_t) * nframes, hipMemcpyDeviceToHost, ctx->stream));
     LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return LDPC_AMD_OK;
+    return check_device_error(ctx);
 }
 
 int ldpc_amd_encode_batch(ldpc_amd_ctx *ctx, int code, int S, int64_t nframes, const uint8_t *source,
@@ -830,7 +854,7 @@ int ldpc_amd_encode_batch(ldpc_amd_ctx *ctx, int code, int S, int64_t nframes, c
     if ((rc = launch_encode(ctx, hc->dev, S, nframes, (const uint8_t *)ctx->stage_in.p, (uint8_t *)ctx->stage_out.p))) return rc;
     LDPC_HIP_TRY(ctx, hipMemcpyAsync(codeword, ctx->stage_out.p, ob, hipMemcpyDeviceToHost, ctx->stream));
     LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return LDPC_AMD_OK;
+    return check_device_error(ctx);
 }
 
 // ---- Reed-Solomon ----------------------------------------------------------------------------------
@@ -940,7 +964,7 @@ int ldpc_amd_rs_encode_batch(ldpc_amd_ctx *ctx, int rs, int S, int64_t nblocks, 
     if ((rc = launch_rs_encode(ctx, *r, S, nblocks, (const uint8_t *)ctx->stage_in.p, (uint8_t *)ctx->stage_out.p))) return rc;
     LDPC_HIP_TRY(ctx, hipMemcpyAsync(codeword, ctx->stage_out.p, ob, hipMemcpyDeviceToHost, ctx->stream));
     LDPC_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return LDPC_AMD_OK;
+    return check_device_error(ctx);
 }
 
 int ldpc_amd_rs_decode_batch(ldpc_amd_ctx *ctx, int rs, int S, int64_t nblocks, const uint16_t *recv_idx,

@@ -116,7 +116,7 @@ struct Knobs {
 };
 // key: "LDPC_AMD_SCATTER_B" or "SCATTER_B" (case-insensitive); value nullptr or "" restores the default.  0 = OK, -1 = unknown key / bad value.
 int knob_set(Knobs &k, const char *key, const char *value);
-void knobs_from_env(Knobs &k);
+bool knobs_from_env(Knobs &k, std::string *rejected);   // false: *rejected = "LDPC_AMD_X=value" of the first value a knob refused
 
 // Growable device scratch
 struct Scratch {
@@ -148,6 +148,7 @@ struct ldpc_amd_ctx {
     ldpc_amd::Scratch stage_in, stage_er, stage_out, stage_i32;  // host-pointer staging
     bool ml_head_valid = false;                   // a packet-mode ML stage has copied its demand there at least once
     unsigned long long *ml_head_host = nullptr;   // pinned: arena words the last packet-mode ML stage asked for
+    int *dev_err_host = nullptr;   // pinned, device-visible: error bits set by kernels (check_device_error turns them into LDPC_AMD_EHIP)
     size_t ml_arena_words = 0;  // current size of the solve-schedule arena (64-bit words), grown on demand
     void *pin = nullptr;        // pinned host bounce block of the small-call path
     size_t pin_cap = 0;
@@ -218,6 +219,8 @@ int scratch_reserve(ldpc_amd_ctx *ctx, Scratch &s, size_t bytes);
 hipEvent_t prof_begin(ldpc_amd_ctx *ctx, int level = 1);
 void prof_end(ldpc_amd_ctx *ctx, int kind, hipEvent_t start);
 int set_error(ldpc_amd_ctx *ctx, int code, const char *fmt, ...);
+// After a synchronisation: LDPC_AMD_EHIP (and the word cleared) if a kernel of this context reported a violated assumption.
+int check_device_error(ldpc_amd_ctx *ctx);
 
 #define LDPC_HIP_TRY(ctx, expr)                                                                   \
     do {                                                                                          \

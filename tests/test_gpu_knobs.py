@@ -37,6 +37,7 @@ KNOBS = [
     ("LDPC_AMD_ML_PI_IMAX", ["0", "3", "17"]),
     ("LDPC_AMD_ML_PI_LDS", ["64", "96"]),
     ("LDPC_AMD_ML_PI_WAVES", ["1", "2"]),
+    ("LDPC_AMD_ML_PI_ADAPTIVE", ["0"]),
     ("LDPC_AMD_RS", ["generic"]),
 ]
 
@@ -121,3 +122,17 @@ def test_environment_is_read_once_at_init_and_configure_rejects_nonsense(oracle,
             assert np.array_equal(c2.decode(h, sym, era)[0], cw)              # a refused value leaves the knob as it was
     finally:
         os.environ.pop("LDPC_AMD_APPLY", None)
+
+
+def test_a_rejected_environment_value_fails_init():
+    """a value a knob does not take must not silently leave the default (an A/B script with a typo would measure the
+    default under the wrong label): ldpc_amd_init refuses, like ldpc_amd_configure does, and names the variable."""
+    for name, val in (("LDPC_AMD_ML_PI_LDS", "16"), ("LDPC_AMD_SCATTER_B", "banana"), ("LDPC_AMD_ML_ARENA_WORDS", str(1 << 40))):
+        os.environ[name] = val
+        try:
+            with pytest.raises(api.LdpcAmdError, match=name):
+                api.Context(0)
+        finally:
+            os.environ.pop(name, None)
+    with api.Context(0) as c:      # and a clean environment still initialises
+        c.selftest()
