@@ -92,6 +92,11 @@ int ldpc_amd_load_builtin_code(ldpc_amd_ctx *ctx, int code_ind, uint64_t coef_se
 int ldpc_amd_register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_ptr, const uint16_t *cols,
                            const uint8_t *coefs);
 int ldpc_amd_code_info(ldpc_amd_ctx *ctx, int code, int *n, int *k, int *nnz);
+/* The static schedules of the systematic encoder of a code handle: info[0] dependency levels of the parity triangle, [1] groups of
+ * the level-collapsed schedule (0: the code has none), [2] accumulators its steps pull in all, [3] scatter entries left, [4] the
+ * longest pull list, [5] 1 = the last packet-mode ldpc_amd_encode_batch of this context ran the grouped schedule.  Diagnostic
+ * (tests, bench.py); no reference counterpart. */
+int ldpc_amd_encode_info(ldpc_amd_ctx *ctx, int code, int info[6]);
 /* Copies the host CSR of a code handle back (cols/coefs may be NULL). */
 int ldpc_amd_code_csr(ldpc_amd_ctx *ctx, int code, uint32_t *row_ptr, uint16_t *cols, uint8_t *coefs);
 

@@ -33,7 +33,7 @@ PROF_KINDS = ("peel", "apply", "ml", "apply_tier2", "ml_solve")
 # every symbol include/ldpc_erasure_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "ldpc_amd_init", "ldpc_amd_cleanup", "ldpc_amd_last_error", "ldpc_amd_set_stream", "ldpc_amd_synchronize", "ldpc_amd_configure",
-    "ldpc_amd_code_params", "ldpc_amd_load_builtin_code", "ldpc_amd_register_code", "ldpc_amd_code_info",
+    "ldpc_amd_code_params", "ldpc_amd_load_builtin_code", "ldpc_amd_register_code", "ldpc_amd_code_info", "ldpc_amd_encode_info",
     "ldpc_amd_code_csr", "ldpc_amd_decode_batch", "ldpc_amd_encode_batch", "ldpc_amd_rs_create",
     "ldpc_amd_rs_generator", "ldpc_amd_rs_encode_batch", "ldpc_amd_rs_decode_batch", "ldpc_amd_rs_bad_blocks", "ldpc_amd_synth_source",
     "ldpc_amd_synth_erasures_uniform", "ldpc_amd_synth_erasures_bursty", "ldpc_amd_data_in", "ldpc_amd_ldpc_erasure_decoder", "ldpc_amd_data_out",
@@ -85,6 +85,7 @@ def load_library():
     L.ldpc_amd_load_builtin_code.argtypes = [vp, i32, u64]
     L.ldpc_amd_register_code.argtypes = [vp, i32, i32, vp, vp, vp]
     L.ldpc_amd_code_info.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.ldpc_amd_encode_info.argtypes = [vp, i32, C.POINTER(i32)]
     L.ldpc_amd_code_csr.argtypes = [vp, i32, vp, vp, vp]
     L.ldpc_amd_decode_batch.argtypes = [vp, i32, i32, i64, vp, vp, i32, i32, vp, vp, vp, vp, C.c_uint]
     L.ldpc_amd_encode_batch.argtypes = [vp, i32, i32, i64, vp, vp, C.c_uint]
@@ -307,6 +308,14 @@ class Context:
                                                   _ptr(out), _ptr(sweeps), _ptr(residual), _ptr(status),
                                                   (DEVICE_PTRS if dev else 0) | (INPLACE if inplace else 0)), "decode_batch")
         return out, sweeps, residual, status
+
+    def encode_info(self, code):
+        """Static schedules of the code's systematic encoder: levels of the parity triangle, groups of the level-collapsed
+        schedule (0: none), accumulators pulled, scatter entries left, longest pull list, and whether the last packet-mode
+        encode of this context ran the grouped schedule."""
+        info = (C.c_int * 6)()
+        self._check(self._L.ldpc_amd_encode_info(self._h, code, info), "encode_info")
+        return dict(zip(("levels", "groups", "pull_entries", "scatter_entries", "max_pull", "last_encode_grouped"), list(info)))
 
     def encode(self, code, source, out=None):
         """source [F,k,S] (or [F,k]) -> codeword [F,n,S] (or [F,n])."""

@@ -105,6 +105,8 @@ static const KnobDesc kKnobs[] = {
     LDPC_KNOB_INT("ENC_CLIST", enc_clist, x == 0 || x == 1),
     LDPC_KNOB_INT("ENC_B", enc_b, x == 128 || x == 256),
     LDPC_KNOB_INT("ENC_LIST", enc_list, x == 0 || x == 1),
+    LDPC_KNOB_INT("ENC_GROUP", enc_group, x == 0 || x == 1),
+    LDPC_KNOB_INT("ENC_CAP", enc_cap, x >= 0 && x <= 64),
     {"RS", [](Knobs &k, const char *v) { if (!strcmp(v, "generic")) k.rs_generic = 1; else if (!strcmp(v, "fast")) k.rs_generic = 0; else return false; return true; },
      [](Knobs &k) { k.rs_generic = 0; }},
     LDPC_KNOB_INT("RS_VW", rs_vw, x == 0 || x == 1 || x == 2 || x == 4),
@@ -402,6 +404,148 @@ static int register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_pt
     }
     const int enc_lst_n = (int)enc_lst.size();
     if (enc_lst.empty()) enc_lst.assign(1, 0xFFFFFFFFu);
+    // ---- grouped static schedule (DevCode::encg_*): levels collapsed offline.  Rows are in topological order (triangle form: the
+    // parity inputs of row r are columns k + j with j < r).  Greedy: row r joins the group of its latest parity input unless it
+    // would then have to pull more than `cap` accumulators (its in-group inputs and theirs, transitively); else it opens the next.
+    std::vector<uint32_t> encg_steps(1, 0), encg_src(1, 0xFFFFFFFFu), encg_ent(1, 0xFFFFFFFFu);
+    std::vector<uint16_t> encg_lvlend(1, 0), encg_ent_off(1, 0);
+    std::vector<uint8_t> encg_invc(1, 1), encg_npull(1, 0);
+    int encg_nlevels = 0, encg_ent_n = 0, encg_pulls = 0, encg_maxpull = 0;
+    const int cap = ctx->knobs.enc_cap;
+    if (enc_nlevels > 1 && cap > 0) {
+        std::vector<int> grp(m, 0);
+        std::vector<std::vector<std::pair<int, uint8_t>>> anc(m);   // (ancestor row, composite coefficient c_ra), rows of r's group
+        std::vector<uint8_t> acc_c(m, 0);
+        std::vector<int> touched;
+        for (int r = 0; r < m; r++) {
+            int gm = -1;
+            for (uint32_t e = row_ptr[r]; e + 1 < row_ptr[r + 1]; e++)
+                if (cols[e] >= k) gm = std::max(gm, grp[cols[e] - k]);
+            if (gm < 0) { grp[r] = 0; continue; }
+            touched.clear();
+            for (uint32_t e = row_ptr[r]; e + 1 < row_ptr[r + 1]; e++) {
+                if (cols[e] < k) continue;
+                const int j = cols[e] - k;
+                if (grp[j] != gm) continue;
+                // val_j = inv_j * (acc_j ^ sum_a c_ja acc_a) enters row r with h_rj
+                const uint8_t f = gf.mul(hc->coefs[e], gf.inv[hc->coefs[row_ptr[j + 1] - 1]]);
+                auto add = [&](int a_, uint8_t c_) {
+                    if (!acc_c[a_]) touched.push_back(a_);   // (a coefficient that cancels to 0 and comes back is listed twice: deduplicated below)
+                    acc_c[a_] ^= c_;
+                };
+                add(j, f);
+                for (const auto &pa : anc[j]) add(pa.first, gf.mul(f, pa.second));
+            }
+            std::sort(touched.begin(), touched.end());
+            touched.erase(std::unique(touched.begin(), touched.end()), touched.end());
+            if ((int)touched.size() > cap) {
+                grp[r] = gm + 1;
+            } else {
+                grp[r] = gm;
+                for (int a_ : touched)
+                    if (acc_c[a_]) anc[r].emplace_back(a_, acc_c[a_]);
+            }
+            for (int a_ : touched) acc_c[a_] = 0;
+        }
+        encg_nlevels = 1 + *std::max_element(grp.begin(), grp.end());
+        // steps by group; inside a group the steps with the longest pull lists first (the rounds of a group even out)
+        std::vector<int> order(m);
+        for (int r = 0; r < m; r++) order[r] = r;
+        std::stable_sort(order.begin(), order.end(), [&](int a_, int b_) {
+            if (grp[a_] != grp[b_]) return grp[a_] < grp[b_];
+            return anc[a_].size() > anc[b_].size();
+        });
+        encg_steps.assign(m, 0); encg_invc.assign(m, 1); encg_lvlend.assign(encg_nlevels + 1, 0);
+        std::vector<uint32_t> slot_of_row(m, 0);
+        for (int s_ = 0; s_ < m; s_++) {
+            const int r = order[s_];
+            slot_of_row[r] = (uint32_t)s_;
+            encg_steps[s_] = (uint32_t)r | ((uint32_t)(k + r) << 16);
+            encg_invc[s_] = gf.inv[hc->coefs[row_ptr[r + 1] - 1]];
+            encg_lvlend[grp[r] + 1] = (uint16_t)(s_ + 1);
+        }
+        for (int L = 1; L <= encg_nlevels; L++) encg_lvlend[L] = std::max(encg_lvlend[L], encg_lvlend[L - 1]);
+        encg_src.assign((size_t)n << cdw_shift, 0xFFFFFFFFu);
+        std::vector<int> fillc(n, 0);
+        for (int r = 0; r < m; r++)
+            for (uint32_t e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
+                const int j = cols[e];
+                if (j == k + r) continue;
+                if (j >= k && grp[j - k] == grp[r]) continue;   // pulled, not scattered
+                encg_src[((size_t)j << cdw_shift) + fillc[j]++] = (slot_of_row[r] * 128u) | ((uint32_t)hc->coefs[e] << 24);
+            }
+        encg_ent.clear(); encg_ent_off.assign(m + 1, 0); encg_npull.assign(m, 0);
+        for (int s_ = 0; s_ < m; s_++) {
+            const int r = order[s_];
+            encg_ent_off[s_] = (uint16_t)encg_ent.size();
+            encg_npull[s_] = (uint8_t)anc[r].size();
+            encg_pulls += (int)anc[r].size();
+            encg_maxpull = std::max(encg_maxpull, (int)anc[r].size());
+            for (const auto &pa : anc[r]) encg_ent.push_back((slot_of_row[pa.first] * 128u) | ((uint32_t)pa.second << 24));
+            for (int i = 0; i < (1 << cdw_shift); i++) {
+                const uint32_t w = encg_src[((size_t)(k + r) << cdw_shift) + i];
+                if (w == 0xFFFFFFFFu) break;
+                encg_ent.push_back(w);
+            }
+            if (encg_ent.size() >= 0xFFFFu) break;
+        }
+        if (encg_ent.size() >= 0xFFFFu) {   // 16-bit offsets: such a code keeps the level-by-level schedule
+            encg_nlevels = 0;
+        } else {
+            encg_ent_off[m] = (uint16_t)encg_ent.size();
+            encg_ent_n = (int)encg_ent.size();
+            // Self-check on bytes (one pseudo-random source word): the grouped schedule, executed the way the kernel executes it,
+            // must give the parity symbols of the row-by-row encoder (ErasureCodes_NonBinaryLDPCSim.m:173-182).
+            std::vector<uint8_t> x(n, 0), accv(m, 0), y(n, 0);
+            uint32_t lcg = 0x9E3779B9u ^ (uint32_t)n;
+            for (int j = 0; j < k; j++) { lcg = lcg * 1664525u + 1013904223u; x[j] = y[j] = (uint8_t)(lcg >> 24); }
+            for (int r = 0; r < m; r++) {
+                uint8_t sacc = 0;
+                for (uint32_t e = row_ptr[r]; e + 1 < row_ptr[r + 1]; e++) sacc ^= gf.mul(hc->coefs[e], x[cols[e]]);
+                x[k + r] = gf.mul(sacc, gf.inv[hc->coefs[row_ptr[r + 1] - 1]]);
+            }
+            for (int j = 0; j < k; j++)
+                for (int i = 0; i < (1 << cdw_shift); i++) {
+                    const uint32_t w = encg_src[((size_t)j << cdw_shift) + i];
+                    if (w == 0xFFFFFFFFu) break;
+                    accv[(w & 0x00FFFFFFu) / 128u] ^= gf.mul((uint8_t)(w >> 24), y[j]);
+                }
+            bool ok = true;
+            for (int L = 1; L <= encg_nlevels && ok; L++) {
+                std::vector<std::pair<int, uint8_t>> vals;
+                for (int s_ = encg_lvlend[L - 1]; s_ < encg_lvlend[L]; s_++) {   // every step of the group reads the accumulators as the group found them
+                    uint8_t a_ = accv[s_];
+                    for (int i = 0; i < encg_npull[s_]; i++) {
+                        const uint32_t w = encg_ent[encg_ent_off[s_] + i];
+                        a_ ^= gf.mul((uint8_t)(w >> 24), accv[(w & 0x00FFFFFFu) / 128u]);
+                    }
+                    vals.emplace_back(s_, gf.mul(a_, encg_invc[s_]));
+                }
+                for (const auto &sv : vals) {
+                    const int s_ = sv.first;
+                    y[encg_steps[s_] >> 16] = sv.second;
+                    for (int i = encg_ent_off[s_] + encg_npull[s_]; i < encg_ent_off[s_ + 1]; i++) {
+                        const uint32_t w = encg_ent[i];
+                        const int tgt_slot = (int)((w & 0x00FFFFFFu) / 128u);
+                        if (tgt_slot >= encg_lvlend[L - 1] && tgt_slot < encg_lvlend[L]) ok = false;   // a scatter inside the group would race with the pulls
+                        accv[tgt_slot] ^= gf.mul((uint8_t)(w >> 24), sv.second);
+                    }
+                }
+            }
+            ok = ok && (x == y);
+            if (!ok) {
+                delete hc;
+                return set_error(ctx, LDPC_AMD_EHIP, "internal: the grouped encode schedule failed its self-check (n=%d, k=%d, cap=%d)", n, k, cap);
+            }
+        }
+        if (encg_nlevels == 0) {
+            encg_steps.assign(1, 0); encg_src.assign(1, 0xFFFFFFFFu); encg_ent.assign(1, 0xFFFFFFFFu);
+            encg_lvlend.assign(1, 0); encg_ent_off.assign(1, 0); encg_invc.assign(1, 1); encg_npull.assign(1, 0);
+            encg_ent_n = 0;
+        }
+    }
+    hc->enc_info[0] = enc_nlevels; hc->enc_info[1] = encg_nlevels; hc->enc_info[2] = encg_pulls;
+    hc->enc_info[3] = encg_ent_n - encg_pulls; hc->enc_info[4] = encg_maxpull;
     // encoder: source rows in the order of their column degree (every check is a step of the static schedule, so a row's
     // degree IS the number of accumulators it feeds): the row pieces a wavefront handles at once then take the same number
     // of edge turns
@@ -419,13 +563,18 @@ static int register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_pt
     d.maxcoldeg = maxcoldeg; d.cdw_shift = cdw_shift;
     d.enc_nlevels = enc_nlevels;
     d.enc_lst_n = enc_lst_n;
+    d.encg_nlevels = encg_nlevels; d.encg_ent_n = encg_ent_n;
     int rc;
     if ((rc = upload(ctx, hc, hc->row_ptr, &d.row_ptr)) || (rc = upload(ctx, hc, edges, &d.edges)) ||
         (rc = upload(ctx, hc, ell_col, &d.ell_col)) || (rc = upload(ctx, hc, ell_logc, &d.ell_logc)) ||
         (rc = upload(ctx, hc, ell_coef, &d.ell_coef)) || (rc = upload(ctx, hc, ell_pk, &d.ell_pk)) || (rc = upload(ctx, hc, cell, &d.cell)) ||
         (rc = upload(ctx, hc, enc_src, &d.enc_src)) || (rc = upload(ctx, hc, enc_order, &d.enc_order)) || (rc = upload(ctx, hc, enc_invc, &d.enc_invc)) ||
         (rc = upload(ctx, hc, enc_steps, &d.enc_steps)) || (rc = upload(ctx, hc, enc_lvlend, &d.enc_lvlend)) ||
-        (rc = upload(ctx, hc, enc_lst, &d.enc_lst)) || (rc = upload(ctx, hc, enc_lst_off, &d.enc_lst_off))) {
+        (rc = upload(ctx, hc, enc_lst, &d.enc_lst)) || (rc = upload(ctx, hc, enc_lst_off, &d.enc_lst_off)) ||
+        (rc = upload(ctx, hc, encg_steps, &d.encg_steps)) || (rc = upload(ctx, hc, encg_lvlend, &d.encg_lvlend)) ||
+        (rc = upload(ctx, hc, encg_invc, &d.encg_invc)) || (rc = upload(ctx, hc, encg_src, &d.encg_src)) ||
+        (rc = upload(ctx, hc, encg_ent, &d.encg_ent)) || (rc = upload(ctx, hc, encg_ent_off, &d.encg_ent_off)) ||
+        (rc = upload(ctx, hc, encg_npull, &d.encg_npull))) {
         free_code(hc);
         return rc;
     }
@@ -741,6 +890,16 @@ int ldpc_amd_code_info(ldpc_amd_ctx *ctx, int code, int *n, int *k, int *nnz)
     if (n) *n = hc->n;
     if (k) *k = hc->k;
     if (nnz) *nnz = hc->nnz;
+    return LDPC_AMD_OK;
+}
+
+int ldpc_amd_encode_info(ldpc_amd_ctx *ctx, int code, int info[6])
+{
+    HostCode *hc = get_code(ctx, code);
+    if (!hc) return ctx ? set_error(ctx, LDPC_AMD_ENOCODE, "unknown code handle %d", code) : LDPC_AMD_EINVAL;
+    if (!info) return set_error(ctx, LDPC_AMD_EINVAL, "info must not be null");
+    for (int i = 0; i < 5; i++) info[i] = hc->enc_info[i];
+    info[5] = ctx->last_enc_grouped;
     return LDPC_AMD_OK;
 }
 

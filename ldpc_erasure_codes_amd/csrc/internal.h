@@ -58,6 +58,22 @@ struct DevCode {
     const uint32_t *enc_lst;     // [enc_lst_n] the enc_src lists of the parity symbols, compact, in schedule order (level phase of the encoder)
     const uint16_t *enc_lst_off; // [m + 1] step -> first word of its list
     int enc_lst_n;               // 0: not available (more than 65534 words)
+    // Grouped static encode schedule (round 4; DESIGN.md section 4.2 "encoder: levels collapsed offline").  The parity triangle's
+    // dependency levels (27 for (2040,1530), 100 for (4080,3060)) are a chain of barriers in which the workgroup streams nothing.
+    // The schedule is static per code, so the host collapses consecutive levels into GROUPS: a step of a group does not wait for
+    // the in-group parities it depends on but PULLS their raw accumulators with composite coefficients
+    //     val_r = inv_r * (acc_r ^ XOR_a c_ra * acc_a),   c_ra = sum over the dependency paths a -> r of prod (h * inv)
+    // (GF(256) products are associative and distributive: the same bytes), and an in-group parity is not scattered into in-group
+    // accumulators.  One barrier per group; a step pulls at most ENC_CAP accumulators.
+    const uint32_t *encg_steps;   // [m] row | (k+row) << 16, sorted by group
+    const uint16_t *encg_lvlend;  // [encg_nlevels + 1] end offsets of the groups
+    const uint8_t *encg_invc;     // [m]
+    const uint32_t *encg_src;     // [n][1 << cdw_shift] like enc_src, slots of the grouped order, in-group parity edges left out
+    const uint32_t *encg_ent;     // [encg_ent_n] per step: its pull entries, then its scatter entries (slot * 128 | coef << 24)
+    const uint16_t *encg_ent_off; // [m + 1]
+    const uint8_t *encg_npull;    // [m] how many of a step's entries are pulls
+    int encg_nlevels;             // number of groups, 0: no grouped schedule
+    int encg_ent_n;
 };
 
 struct HostCode {
@@ -66,6 +82,7 @@ struct HostCode {
     std::vector<uint16_t> cols;
     std::vector<uint8_t> coefs;
     DevCode dev{};
+    int enc_info[5] = {0, 0, 0, 0, 0};   // levels of the plain static schedule, groups, pull entries, scatter entries, longest pull list
     std::vector<void *> allocs;
 };
 
@@ -109,6 +126,8 @@ struct Knobs {
     int enc_clist = 1;           // ENC_CLIST: encoder -- the level phase reads the parity symbols' lists from LDS (compact copy); 0: from global memory
     int enc_b = 128;             // ENC_B: encoder piece size (128: two workgroups per CU; 256: the decoder's plan)
     int enc_list = 0;            // ENC_LIST: encoder streams the source rows in the order of their column degree
+    int enc_group = 1;           // ENC_GROUP: encoder runs the grouped (level-collapsed) static schedule when the code has one; 0: level by level
+    int enc_cap = 8;             // ENC_CAP: read when a code is REGISTERED -- a step of the grouped schedule pulls at most this many accumulators (0: no grouped schedule)
     int rs_generic = 0;          // RS=generic: RS decode always through the generic LDS kernel
     int rs_vw = 0;               // RS_VW: dwords per lane of the packet RS kernel (0 = auto = 1; 2 and 4 where S allows)
     int host_pipeline = 1;       // HOST_PIPELINE: chunked upload / compute / download pipeline for large host buffers
@@ -174,6 +193,7 @@ struct ldpc_amd_ctx {
     std::vector<hipEvent_t> prof_pool;
     std::string prof_names[LDPC_AMD_PROF_KINDS];   // template instantiation the last launch of each kind used
     int last_plan[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // launch plan of the last decode (ldpc_amd_last_plan)
+    int last_enc_grouped = 0;                      // the last packet-mode encode ran the grouped static schedule (ldpc_amd_encode_info)
 };
 
 namespace ldpc_amd {

@@ -609,6 +609,7 @@ struct ScatterArgs {
     int lds_soc_bytes;        // size of the row-kind / row-list region
     int enc_list;             // encode: stream the source rows in DevCode::enc_order
     int enc_clist;            // encode: the level phase reads DevCode::enc_lst from LDS (copied over the dead row tables at lds_soc)
+    int enc_group;            // encode: the grouped static schedule (DevCode::encg_*: levels collapsed offline, steps pull in-group accumulators)
     int *err;                 // pinned host word (ldpc_amd_ctx::dev_err_host): a kernel whose assumptions do not hold reports here
     int dbg;                  // diagnostic build only (-DLDPC_AMD_MLDBG): 32768 = tier 1 also takes the frames with more than tcap steps,
                               // cut off at tcap steps (WRONG bytes: prices the first pass of a level-split tier 2)
@@ -734,10 +735,11 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
 #else
     const int nsteps = a.static_sched ? cd.m : (int)a.sched_hdr[2 * f];
 #endif
-    const int nlev = a.static_sched ? cd.enc_nlevels : (int)a.sched_hdr[2 * f + 1];
-    const uint32_t *gs = a.static_sched ? cd.enc_steps : a.sched_steps + f * cd.m;
-    const uint16_t *gle = a.static_sched ? cd.enc_lvlend : a.sched_lvlend + f * (cd.m + 1);
-    const uint8_t *gic = a.static_sched ? cd.enc_invc : a.sched_invc + f * cd.m;
+    const bool grouped = a.static_sched && a.enc_group;
+    const int nlev = a.static_sched ? (grouped ? cd.encg_nlevels : cd.enc_nlevels) : (int)a.sched_hdr[2 * f + 1];
+    const uint32_t *gs = a.static_sched ? (grouped ? cd.encg_steps : cd.enc_steps) : a.sched_steps + f * cd.m;
+    const uint16_t *gle = a.static_sched ? (grouped ? cd.encg_lvlend : cd.enc_lvlend) : a.sched_lvlend + f * (cd.m + 1);
+    const uint8_t *gic = a.static_sched ? (grouped ? cd.encg_invc : cd.enc_invc) : a.sched_invc + f * cd.m;
     const uint8_t *erf = a.erased ? a.erased + f * (int64_t)n : nullptr;
     // Set-up costs one global-memory latency: everything that comes from global memory (this thread's steps, erasure
     // flags, level offsets, multiply tables) is requested first, the LDS is initialised while the loads are in flight.
@@ -942,7 +944,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     auto in_row = [&](int j) { return fin0 + (__umul24((uint32_t)j, S32) + lo16); };
     auto out_row = [&](int j) { return fout0 + (__umul24((uint32_t)j, S32) + lo16); };
     // H's static column lists (check | coef << 16); the encoder's are already in (slot | coef << 16) form
-    const uint32_t *spad = a.static_sched ? cd.enc_src : cd.cell;
+    const uint32_t *spad = a.static_sched ? (grouped ? cd.encg_src : cd.enc_src) : cd.cell;
     const bool translate = !a.static_sched;
 
     // multiplies v into the accumulators of the steps that symbol j feeds: ew = the symbol's list, entry t held by
@@ -1127,7 +1129,27 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     // is done with; round 3: its level phase was 59 % of a workgroup's time with one global list load per level, tools/stamp_encode.py.)
     const uint32_t *clist = reinterpret_cast<const uint32_t *>(smem + a.lds_soc);
     const uint16_t *coff = reinterpret_cast<const uint16_t *>(smem + a.lds_soc + 4 * cd.enc_lst_n);
-    if (a.static_sched && a.enc_clist) {
+    // Grouped schedule: per step its pull entries, then its scatter entries, 3 bytes each in LDS (slot u16 | coef u8: the 4-byte
+    // words would not fit beside all m accumulators in half a CU's LDS), one offset array and the pull counts.
+    const int gent = cd.encg_ent_n, gent2 = (gent + 7) & ~7;
+    const uint16_t *g_slot = reinterpret_cast<const uint16_t *>(smem + a.lds_soc);
+    const uint8_t *g_coef = smem + a.lds_soc + 2 * gent2;
+    const uint16_t *g_off = reinterpret_cast<const uint16_t *>(smem + a.lds_soc + 3 * gent2);
+    const uint8_t *g_np = smem + a.lds_soc + 3 * gent2 + 2 * ((cd.m + 8) & ~7);
+    if (grouped) {
+        uint16_t *ws = reinterpret_cast<uint16_t *>(smem + a.lds_soc);
+        uint8_t *wc = smem + a.lds_soc + 2 * gent2;
+        uint16_t *wo = reinterpret_cast<uint16_t *>(smem + a.lds_soc + 3 * gent2);
+        uint8_t *wn = smem + a.lds_soc + 3 * gent2 + 2 * ((cd.m + 8) & ~7);
+        for (int i = tid; i < gent; i += nthr) {
+            const uint32_t w = cd.encg_ent[i];
+            ws[i] = (uint16_t)((w & 0x00FFFFFFu) >> 7);   // slot (the words hold slot * 128)
+            wc[i] = (uint8_t)(w >> 24);
+        }
+        for (int i = tid; i <= nsteps; i += nthr) wo[i] = cd.encg_ent_off[i];
+        for (int i = tid; i < nsteps; i += nthr) wn[i] = cd.encg_npull[i];
+        __syncthreads();
+    } else if (a.static_sched && a.enc_clist) {
         uint32_t *cw_ = reinterpret_cast<uint32_t *>(smem + a.lds_soc);
         uint16_t *co_ = reinterpret_cast<uint16_t *>(smem + a.lds_soc + 4 * cd.enc_lst_n);
         for (int i = tid; i < cd.enc_lst_n; i += nthr) cw_[i] = cd.enc_lst[i];
@@ -1135,11 +1157,13 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         __syncthreads();
     }
     auto phase_b = [&](auto lds_tag) {
-        constexpr int MODE = decltype(lds_tag)::value;   // 0: lists from global memory, 1: padded lists in LDS, 2: compact lists in LDS
+        constexpr int MODE = decltype(lds_tag)::value;   // 0: lists from global memory, 1: padded lists in LDS, 2: compact lists in LDS,
+                                                         // 3: grouped static schedule (pull + scatter entries in LDS, 3 bytes each)
         constexpr bool LL = MODE != 0;
         auto load_list = [&](int s, int s1, uint32_t (&ew)[KQ]) {
 #pragma unroll
             for (int q = 0; q < KQ; q++) ew[q] = 0xFFFFFFFFu;
+            if (MODE == 3) return;   // (the grouped schedule builds its lists where it uses them)
             if (s < s1) {
                 if (MODE == 2) {
                     const uint32_t o0 = coff[s], o1 = coff[s + 1];
@@ -1172,6 +1196,34 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
                 } else {
                     load_list(s, s1, ew);
                 }
+                if (MODE == 3) {
+                    // a group of collapsed levels: the step adds the raw accumulators of its in-group ancestors (composite
+                    // coefficients, DevCode::encg_ent) to its own before the division -- no step of the group waits for another
+                    const bool on = s < s1;
+                    const uint32_t o0 = on ? g_off[s] : 0u, o1 = on ? g_off[s + 1] : 0u, np = on ? g_np[s] : 0u;
+                    U4 a16 = {0, 0, 0, 0};
+                    if (on) a16 = kSplit ? lds_read16_split(acc + (size_t)s * B, gl, B / 2)
+                                         : *reinterpret_cast<const U4 *>(acc + (size_t)s * B + gl * 16);
+                    for (uint32_t i = 0; __any(i < np); i++) {
+                        if (i < np) {
+                            const uint32_t sl_ = g_slot[o0 + i], cf = g_coef[o0 + i];
+                            const U4 src = kSplit ? lds_read16_split(acc + (size_t)sl_ * B, gl, B / 2)
+                                                  : *reinterpret_cast<const U4 *>(acc + (size_t)sl_ * B + gl * 16);
+                            gfmac16(a16, lds_multab(mt, cf), src);
+                        }
+                    }
+                    if (on) {
+                        val = gfmul16(lds_multab(mt, invc[s]), a16);
+                        stream_store16<NT>(out_row(tgt[s]), val);
+                    }
+#pragma unroll
+                    for (int q = 0; q < KQ; q++) {
+                        const uint32_t idx = o0 + np + (uint32_t)(gl + q * LPR);
+                        ew[q] = idx < o1 ? ((accbase + (uint32_t)g_slot[idx] * (uint32_t)B) | ((uint32_t)g_coef[idx] << 24)) : 0xFFFFFFFFu;
+                    }
+                    scatter(val, ew);
+                    continue;
+                }
                 if (s < s1) {
                     const int t = tgt[s];
                     const U4 a16 = kSplit ? lds_read16_split(acc + (size_t)s * B, gl, B / 2)
@@ -1186,7 +1238,8 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
             __syncthreads();
         }
     };
-    if (a.static_sched && a.enc_clist) phase_b(std::integral_constant<int, 2>{});
+    if (grouped) phase_b(std::integral_constant<int, 3>{});
+    else if (a.static_sched && a.enc_clist) phase_b(std::integral_constant<int, 2>{});
     else if (lds_lists) phase_b(std::integral_constant<int, 1>{});
     else phase_b(std::integral_constant<int, 0>{});
     LDPC_STAMP(15);  // scatter: level phase
@@ -2067,12 +2120,17 @@ int launch_encode(ldpc_amd_ctx *ctx, const DevCode &cd, int S, int64_t nframes, 
             // ONE workgroup per CU.  With 128-byte pieces and the tables the static schedule does not need left out (check ->
             // slot table, received-row list) two workgroups fit, and one streams while the other runs its 27 levels.
             const int eb = kn.enc_b;
+            // grouped static schedule (levels collapsed offline): used when the code has one and its lists fit the LDS plan below
+            bool grouped = kn.enc_group != 0 && cd.encg_nlevels > 0;
+            const int nlev_plan = grouped ? cd.encg_nlevels : cd.enc_nlevels;
+            const int gent2 = (cd.encg_ent_n + 7) & ~7;
+            const int need_g = 3 * gent2 + 2 * ((cd.m + 8) & ~7) + ((cd.m + 15) & ~15);
             if (plan.lpr == 16 && eb == 128 && (S % 128) == 0) {
                 ScatterPlan q = plan;
                 int off = 0;
                 q.o_tgt = off; off += align_up(2 * cd.m, 16);
                 q.o_invc = off; off += align_up(cd.m, 16);
-                q.o_lvl = off; off += align_up(2 * (cd.m + 2), 16);
+                q.o_lvl = off; off += align_up(2 * (nlev_plan + 2), 16);   // (level / group offsets: as many as this schedule has)
                 q.o_ctr = off; off += 288;
                 q.o_mt = off;                // (the tables sit in front of the accumulators: added to the total below)
                 q.o_soc = off; off += align_up(2 * cd.k, 16) >= cd.n ? align_up(2 * cd.k, 16) : align_up(cd.n, 16);   // row kinds (u8), then the source-row list (u16 [k])
@@ -2087,10 +2145,22 @@ int launch_encode(ldpc_amd_ctx *ctx, const DevCode &cd, int S, int64_t nframes, 
             // the compact lists of the parity symbols for the level phase: over the row tables (dead by then), which end the layout --
             // the allocation grows by what they need beyond those tables when that still fits
             int enc_clist = 0;
-            if (kn.enc_clist && cd.enc_lst_n > 0) {
+            const int soc_off = 8192 + align_up(cd.m * 16 * plan.lpr, 16) + plan.o_soc;
+            const int limit = (plan.two_tier && plan.lpr == 8) ? kLdsMax / 2 : kLdsMax;
+            if (grouped) {
+                if (soc_off + need_g <= limit) plan.lds1 = plan.lds2 = std::max(plan.lds1, soc_off + need_g);
+                else grouped = false;   // (the plan's level table was sized for the groups: still enough? no -- re-plan below)
+            }
+            if (!grouped && kn.enc_group != 0 && cd.encg_nlevels > 0 && nlev_plan != cd.enc_nlevels) {
+                // the lists did not fit: the level table of the plan above was sized for the groups, the plain schedule has more levels
+                const int saved = ctx->knobs.enc_group;
+                ctx->knobs.enc_group = 0;
+                const int rc_ = launch_encode(ctx, cd, S, nframes, src, cw);
+                ctx->knobs.enc_group = saved;
+                return rc_;
+            }
+            if (!grouped && kn.enc_clist && cd.enc_lst_n > 0) {
                 const int need = 4 * cd.enc_lst_n + align_up(2 * (cd.m + 1), 16);
-                const int soc_off = 8192 + align_up(cd.m * 16 * plan.lpr, 16) + plan.o_soc;
-                const int limit = (plan.two_tier && plan.lpr == 8) ? kLdsMax / 2 : kLdsMax;
                 if (soc_off + need <= limit) {
                     enc_clist = 1;
                     plan.lds1 = plan.lds2 = std::max(plan.lds1, soc_off + need);
@@ -2099,6 +2169,8 @@ int launch_encode(ldpc_amd_ctx *ctx, const DevCode &cd, int S, int64_t nframes, 
             ScatterArgs sa{};
             sa.code = cd; sa.S = S; sa.nslices = plan.nslices; sa.nframes = nframes; sa.sym = src; sa.erased = nullptr; sa.out = cw;
             sa.in_rows = cd.k; sa.static_sched = 1; sa.enc_clist = enc_clist; sa.err = ctx->dev_err_host;
+            sa.enc_group = grouped ? 1 : 0;
+            ctx->last_enc_grouped = sa.enc_group;
             sa.enc_list = kn.enc_list;   // measured slower (4.62 vs 4.14 ms): off unless asked for
             return launch_scatter(ctx, plan, sa, nullptr);
         }
