@@ -691,7 +691,7 @@ __device__ __forceinline__ void stream_store16(uint8_t *p, const U4 &v)
     }
 }
 
-template <int LPR, int R, bool NT, bool INPLACE>
+template <int LPR, int R, bool NT, bool INPLACE, int WPE = 4>
 __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned char *smem, const int64_t f, const int sl)
 {
     constexpr int RPW = 64 / LPR;              // row pieces per wave instruction
@@ -1157,13 +1157,11 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         __syncthreads();
     }
     auto phase_b = [&](auto lds_tag) {
-        constexpr int MODE = decltype(lds_tag)::value;   // 0: lists from global memory, 1: padded lists in LDS, 2: compact lists in LDS,
-                                                         // 3: grouped static schedule (pull + scatter entries in LDS, 3 bytes each)
+        constexpr int MODE = decltype(lds_tag)::value;   // 0: lists from global memory, 1: padded lists in LDS, 2: compact lists in LDS
         constexpr bool LL = MODE != 0;
         auto load_list = [&](int s, int s1, uint32_t (&ew)[KQ]) {
 #pragma unroll
             for (int q = 0; q < KQ; q++) ew[q] = 0xFFFFFFFFu;
-            if (MODE == 3) return;   // (the grouped schedule builds its lists where it uses them)
             if (s < s1) {
                 if (MODE == 2) {
                     const uint32_t o0 = coff[s], o1 = coff[s + 1];
@@ -1196,34 +1194,6 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
                 } else {
                     load_list(s, s1, ew);
                 }
-                if (MODE == 3) {
-                    // a group of collapsed levels: the step adds the raw accumulators of its in-group ancestors (composite
-                    // coefficients, DevCode::encg_ent) to its own before the division -- no step of the group waits for another
-                    const bool on = s < s1;
-                    const uint32_t o0 = on ? g_off[s] : 0u, o1 = on ? g_off[s + 1] : 0u, np = on ? g_np[s] : 0u;
-                    U4 a16 = {0, 0, 0, 0};
-                    if (on) a16 = kSplit ? lds_read16_split(acc + (size_t)s * B, gl, B / 2)
-                                         : *reinterpret_cast<const U4 *>(acc + (size_t)s * B + gl * 16);
-                    for (uint32_t i = 0; __any(i < np); i++) {
-                        if (i < np) {
-                            const uint32_t sl_ = g_slot[o0 + i], cf = g_coef[o0 + i];
-                            const U4 src = kSplit ? lds_read16_split(acc + (size_t)sl_ * B, gl, B / 2)
-                                                  : *reinterpret_cast<const U4 *>(acc + (size_t)sl_ * B + gl * 16);
-                            gfmac16(a16, lds_multab(mt, cf), src);
-                        }
-                    }
-                    if (on) {
-                        val = gfmul16(lds_multab(mt, invc[s]), a16);
-                        stream_store16<NT>(out_row(tgt[s]), val);
-                    }
-#pragma unroll
-                    for (int q = 0; q < KQ; q++) {
-                        const uint32_t idx = o0 + np + (uint32_t)(gl + q * LPR);
-                        ew[q] = idx < o1 ? ((accbase + (uint32_t)g_slot[idx] * (uint32_t)B) | ((uint32_t)g_coef[idx] << 24)) : 0xFFFFFFFFu;
-                    }
-                    scatter(val, ew);
-                    continue;
-                }
                 if (s < s1) {
                     const int t = tgt[s];
                     const U4 a16 = kSplit ? lds_read16_split(acc + (size_t)s * B, gl, B / 2)
@@ -1238,7 +1208,59 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
             __syncthreads();
         }
     };
-    if (grouped) phase_b(std::integral_constant<int, 3>{});
+    // Grouped static schedule (encoder; DevCode::encg_*): a group of collapsed levels per barrier.  A step adds the raw accumulators
+    // of its in-group ancestors (composite coefficients) to its own before the division -- no step of a group waits for another.
+    // (U steps per lane group and trip: two steps carried through the chain of LDS round trips at once measured SLOWER on the
+    // (4080,3060) encoder -- 5.44 against 5.14 ms per 2048 frames, same box -- so one.)
+    auto phase_g = [&]() {
+        constexpr int U = 1;
+        for (int L = 1; L <= nlev; L++) {
+            const int s0 = lvlend[L - 1], s1 = lvlend[L];
+            for (int sb = s0 + wave * RPW; sb < s1; sb += U * nw * RPW) {
+                bool on[U];
+                uint32_t su[U], o0[U], o1[U], np[U], npmax = 0;
+                U4 a16[U], val[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    su[u] = (uint32_t)(sb + u * nw * RPW + g);
+                    on[u] = (int)su[u] < s1;
+                    o0[u] = on[u] ? g_off[su[u]] : 0u; o1[u] = on[u] ? g_off[su[u] + 1] : 0u; np[u] = on[u] ? g_np[su[u]] : 0u;
+                    a16[u] = U4{0, 0, 0, 0}; val[u] = U4{0, 0, 0, 0};
+                    if (on[u]) a16[u] = kSplit ? lds_read16_split(acc + (size_t)su[u] * B, gl, B / 2)
+                                               : *reinterpret_cast<const U4 *>(acc + (size_t)su[u] * B + gl * 16);
+                    npmax = max(npmax, np[u]);
+                }
+                for (uint32_t i = 0; __any(i < npmax); i++) {
+#pragma unroll
+                    for (int u = 0; u < U; u++)
+                        if (i < np[u]) {
+                            const uint32_t sl_ = g_slot[o0[u] + i], cf = g_coef[o0[u] + i];
+                            const U4 src = kSplit ? lds_read16_split(acc + (size_t)sl_ * B, gl, B / 2)
+                                                  : *reinterpret_cast<const U4 *>(acc + (size_t)sl_ * B + gl * 16);
+                            gfmac16(a16[u], lds_multab(mt, cf), src);
+                        }
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++)
+                    if (on[u]) {
+                        val[u] = gfmul16(lds_multab(mt, invc[su[u]]), a16[u]);
+                        stream_store16<NT>(out_row(tgt[su[u]]), val[u]);
+                    }
+                uint32_t ew[U][KQ];
+#pragma unroll
+                for (int u = 0; u < U; u++)
+#pragma unroll
+                    for (int q = 0; q < KQ; q++) {
+                        const uint32_t idx = o0[u] + np[u] + (uint32_t)(gl + q * LPR);
+                        ew[u][q] = idx < o1[u] ? ((accbase + (uint32_t)g_slot[idx] * (uint32_t)B) | ((uint32_t)g_coef[idx] << 24)) : 0xFFFFFFFFu;
+                    }
+#pragma unroll
+                for (int u = 0; u < U; u++) scatter(val[u], ew[u]);
+            }
+            __syncthreads();
+        }
+    };
+    if (grouped) phase_g();
     else if (a.static_sched && a.enc_clist) phase_b(std::integral_constant<int, 2>{});
     else if (lds_lists) phase_b(std::integral_constant<int, 1>{});
     else phase_b(std::integral_constant<int, 0>{});
@@ -1270,12 +1292,12 @@ __global__ __launch_bounds__(1024, WPE) void ldpc_scatter_kernel(ScatterArgs a)
 #else
     if (!a.static_sched && (int)a.sched_hdr[2 * f] > a.tcap) return;
 #endif
-    scatter_frame<LPR, R, NT, INPLACE>(a, smem, f, sl);
+    scatter_frame<LPR, R, NT, INPLACE, WPE>(a, smem, f, sl);
 }
 
 // Tier 2: the few frames with many steps (LDS sized for m accumulators), grid-stride over the compacted list.
-template <int LPR, int R, bool NT, bool INPLACE>
-__global__ __launch_bounds__(1024) void ldpc_scatter_big_kernel(ScatterArgs a)
+template <int LPR, int R, bool NT, bool INPLACE, int WPE = 4>
+__global__ __launch_bounds__(1024, WPE) void ldpc_scatter_big_kernel(ScatterArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // work items (frame, slice) are handed out through a device counter, first come first served: their cost varies with the
@@ -1288,7 +1310,7 @@ __global__ __launch_bounds__(1024) void ldpc_scatter_big_kernel(ScatterArgs a)
         __syncthreads();
         const int it = *slot;
         if (it >= items) break;
-        scatter_frame<LPR, R, NT, INPLACE>(a, smem, a.big_list[2 + it / a.nslices], (int)(it % a.nslices));
+        scatter_frame<LPR, R, NT, INPLACE, WPE>(a, smem, a.big_list[2 + it / a.nslices], (int)(it % a.nslices));
     }
 }
 
@@ -1648,6 +1670,27 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
             ctx->prof_names[LDPC_AMD_PROF_APPLY_TIER2] = nm;
         }
         hipEvent_t ev2 = prof_begin(ctx, 2);
+        // SCATTER_T2B = 128: tier 2 with 128-byte pieces -- all m accumulators then take half a CU's LDS, so TWO tier-2 workgroups
+        // share a CU (one streams while the other sets up / runs its levels), at twice the per-byte instruction count of an edge turn
+        const int tail_b = p.lds2 - sa.code.m * 16 * p.lpr;   // tables + small arrays of the plan
+        const bool t2_128 = LPR == 16 && kn.scatter_t2b == 128 && (sa.S % 128) == 0 && sa.code.m * 128 + tail_b <= kLdsMax / 2;
+        if (t2_128) {
+            ScatterPlan p2 = p;
+            p2.lpr = 8; p2.nslices = sa.S / 128; p2.lds2 = sa.code.m * 128 + tail_b;
+            sa.nslices = p2.nslices;
+            scatter_set_lds(sa, p2, sa.code.m);
+            const dim3 g3((unsigned)std::min<int64_t>(sa.nframes * sa.nslices, (int64_t)ctx->sm_count * 2));
+            ctx->prof_names[LDPC_AMD_PROF_APPLY_TIER2] = std::string("ldpc_scatter_big_kernel<8, 2, ") + (nt ? "true" : "false") + ", " + (ip ? "true" : "false") + ", 8>";
+#define LDPC_SCATTER_T2B(NTV, IPV)                                                                           \
+    {                                                                                                        \
+        auto kfn = ldpc_scatter_big_kernel<8, 2, NTV, IPV, 8>;                                               \
+        LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(kfn)));                               \
+        hipLaunchKernelGGL(kfn, g3, dim3(1024), (size_t)p2.lds2, ctx->stream, sa);                           \
+    }
+            if (ip) { if (nt) LDPC_SCATTER_T2B(true, true) else LDPC_SCATTER_T2B(false, true) }
+            else { if (nt) LDPC_SCATTER_T2B(true, false) else LDPC_SCATTER_T2B(false, false) }
+#undef LDPC_SCATTER_T2B
+        } else
         if (ip) { if (nt) LDPC_SCATTER_T2(true, true) else LDPC_SCATTER_T2(false, true) }
         else { if (nt) LDPC_SCATTER_T2(true, false) else LDPC_SCATTER_T2(false, false) }
 #undef LDPC_SCATTER_T2_R

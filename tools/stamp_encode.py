@@ -12,9 +12,11 @@ PHASES = {12: "set-up (tables, lists, zeroing)", 13: "streaming phase", 14: "wai
 
 
 def main():
-    so = "/tmp/libldpc_erasure_amd_stamps.so"
+    so = os.path.join(ROOT, "tools", "bin", "libldpc_erasure_amd_stamps.so")   # prebuilt by tools/build_stamps.sh (travels with gpurun)
     src = os.path.join(ROOT, "ldpc_erasure_codes_amd", "csrc")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-strict-aliasing",
+    if not os.path.exists(so):
+        so = "/tmp/libldpc_erasure_amd_stamps.so"
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-strict-aliasing",
                            "-DLDPC_AMD_STAMPS", "-shared", "-o", so, os.path.join(src, "kernels.hip"), os.path.join(src, "api.cpp"), os.path.join(src, "wire.cpp")])
     import torch
     from ldpc_erasure_codes_amd import api, codes
