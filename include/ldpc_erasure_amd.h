@@ -181,6 +181,11 @@ typedef struct { /* error_type, OpenCL/device/ldpc_erasure_decoder_top.cl:46-49 
  * decoder call draws the stream chunk by chunk (memory O(chunk), so N_T = 1e6 ... 2e8 of the paper's Table I runs). */
 int ldpc_amd_data_in(ldpc_amd_ctx *ctx, const ldpc_amd_symbol_type *data_in, unsigned short nldpc, int seed,
                      int PER_numerator_div_64, int code_ind, long numFrames);
+/* The same source armed at frame `firstFrame` of its stream: the run covers frames [firstFrame, firstFrame + numFrames) of what
+ * ldpc_amd_data_in(..., firstFrame + numFrames) would draw -- one rank's shard of a multi-device run
+ * (ldpc_amd_group_fpga_run, include/ldpc_erasure_amd_multi.h).  No FPGA counterpart (one device there). */
+int ldpc_amd_data_in_at(ldpc_amd_ctx *ctx, const ldpc_amd_symbol_type *data_in, unsigned short nldpc, int seed,
+                        int PER_numerator_div_64, int code_ind, long numFrames, long firstFrame);
 /* ldpc_erasure_decoder(short num_iter, int code_ind) (ldpc_erasure_decoder_perf_tests.cl:30): decodes the
  * frames of the last ldpc_amd_data_in with the binary packet-XOR message-passing decoder, frame loop like :52-238:
  * chunk by chunk  source -> decode -> running counters {num_frame_errors, num_RS_frame_errors} (:46-47,70-80,229-236).

@@ -36,7 +36,10 @@ EXPORTS = [
     "ldpc_amd_code_params", "ldpc_amd_load_builtin_code", "ldpc_amd_register_code", "ldpc_amd_code_info", "ldpc_amd_encode_info",
     "ldpc_amd_code_csr", "ldpc_amd_decode_batch", "ldpc_amd_encode_batch", "ldpc_amd_rs_create",
     "ldpc_amd_rs_generator", "ldpc_amd_rs_encode_batch", "ldpc_amd_rs_decode_batch", "ldpc_amd_rs_bad_blocks", "ldpc_amd_synth_source",
-    "ldpc_amd_synth_erasures_uniform", "ldpc_amd_synth_erasures_bursty", "ldpc_amd_data_in", "ldpc_amd_ldpc_erasure_decoder", "ldpc_amd_data_out",
+    "ldpc_amd_synth_erasures_uniform", "ldpc_amd_synth_erasures_bursty", "ldpc_amd_data_in", "ldpc_amd_data_in_at",
+    "ldpc_amd_shard_frames", "ldpc_amd_group_create", "ldpc_amd_group_destroy", "ldpc_amd_group_size", "ldpc_amd_group_device", "ldpc_amd_group_ctx",
+    "ldpc_amd_group_last_error", "ldpc_amd_group_load_builtin_code", "ldpc_amd_group_register_code", "ldpc_amd_group_decode_batch",
+    "ldpc_amd_group_decode_resident", "ldpc_amd_group_fpga_run", "ldpc_amd_group_bench_resident", "ldpc_amd_ldpc_erasure_decoder", "ldpc_amd_data_out",
     "ldpc_amd_ldpc_erasure_decoder_perf_tests", "ldpc_amd_fpga_frame_stats", "ldpc_amd_profile_kernel_name", "ldpc_amd_last_plan", "ldpc_amd_ml_stats",
     "ldpc_amd_fec_header_pack", "ldpc_amd_fec_header_unpack", "ldpc_amd_fec_packetize", "ldpc_amd_fec_rx_create",
     "ldpc_amd_fec_rx_destroy", "ldpc_amd_fec_rx_push", "ldpc_amd_fec_rx_push_many", "ldpc_amd_fec_rx_flush", "ldpc_amd_fec_rx_dropped",
@@ -86,6 +89,26 @@ def load_library():
     L.ldpc_amd_register_code.argtypes = [vp, i32, i32, vp, vp, vp]
     L.ldpc_amd_code_info.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.ldpc_amd_encode_info.argtypes = [vp, i32, C.POINTER(i32)]
+    # multi-device layer (include/ldpc_erasure_amd_multi.h)
+    L.ldpc_amd_shard_frames.argtypes = [i64, i32, i32, C.POINTER(i64), C.POINTER(i64)]
+    L.ldpc_amd_shard_frames.restype = None
+    L.ldpc_amd_group_create.argtypes = [i32, C.POINTER(i32), C.POINTER(vp)]
+    L.ldpc_amd_group_destroy.argtypes = [vp]
+    L.ldpc_amd_group_destroy.restype = None
+    L.ldpc_amd_group_size.argtypes = [vp]
+    L.ldpc_amd_group_device.argtypes = [vp, i32]
+    L.ldpc_amd_group_ctx.argtypes = [vp, i32]
+    L.ldpc_amd_group_ctx.restype = vp
+    L.ldpc_amd_group_last_error.argtypes = [vp]
+    L.ldpc_amd_group_last_error.restype = C.c_char_p
+    L.ldpc_amd_group_load_builtin_code.argtypes = [vp, i32, u64]
+    L.ldpc_amd_group_register_code.argtypes = [vp, i32, i32, vp, vp, vp]
+    L.ldpc_amd_group_decode_batch.argtypes = [vp, i32, i32, i64, vp, vp, i32, i32, vp, vp, vp, vp]
+    L.ldpc_amd_group_decode_resident.argtypes = [vp, i32, i32, i64, C.POINTER(vp), C.POINTER(vp), i32, i32, C.POINTER(vp), C.POINTER(vp), vp, vp,
+                                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.ldpc_amd_group_fpga_run.argtypes = [vp, C.c_ushort, i32, i32, i32, C.c_long, C.c_short, i32, C.POINTER(ErrorType)]
+    L.ldpc_amd_group_bench_resident.argtypes = [vp, i32, u64, i32, i64, C.c_double, i32, i32, C.POINTER(C.c_double)]
+    L.ldpc_amd_data_in_at.argtypes = [vp, vp, C.c_ushort, i32, i32, i32, C.c_long, C.c_long]
     L.ldpc_amd_code_csr.argtypes = [vp, i32, vp, vp, vp]
     L.ldpc_amd_decode_batch.argtypes = [vp, i32, i32, i64, vp, vp, i32, i32, vp, vp, vp, vp, C.c_uint]
     L.ldpc_amd_encode_batch.argtypes = [vp, i32, i32, i64, vp, vp, C.c_uint]
@@ -498,3 +521,89 @@ class FecRx:
             self.close()
         except Exception:
             pass
+
+
+def shard_frames(nframes, nranks, rank):
+    """(first, count) of rank's contiguous block: the library's C shard arithmetic (ldpc_amd_shard_frames)."""
+    L = load_library()
+    f0, cnt = C.c_int64(), C.c_int64()
+    L.ldpc_amd_shard_frames(nframes, nranks, rank, C.byref(f0), C.byref(cnt))
+    return f0.value, cnt.value
+
+
+class Group:
+    """The C-level multi-device layer (include/ldpc_erasure_amd_multi.h): nranks contexts, one host thread each; devices may
+    repeat (several ranks on one device: how the layer is tested on a one-GPU box)."""
+
+    def __init__(self, nranks, devices=None):
+        self._L = load_library()
+        h = C.c_void_p()
+        dv = None if devices is None else (C.c_int * nranks)(*devices)
+        rc = self._L.ldpc_amd_group_create(nranks, dv, C.byref(h))
+        if rc != OK:
+            raise LdpcAmdError(f"ldpc_amd_group_create({nranks}) = {rc}: {self._L.ldpc_amd_last_error(None).decode()}")
+        self._h = h
+        self.nranks = nranks
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ldpc_amd_group_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc < 0:
+            raise LdpcAmdError(f"{what} = {rc}: {self._L.ldpc_amd_group_last_error(self._h).decode()}")
+        return rc
+
+    def device(self, rank):
+        return self._L.ldpc_amd_group_device(self._h, rank)
+
+    def load_builtin_code(self, code_ind, coef_seed):
+        return self._check(self._L.ldpc_amd_group_load_builtin_code(self._h, code_ind, coef_seed), "group_load_builtin_code")
+
+    def register_code(self, code):
+        rp = np.ascontiguousarray(code.row_ptr, dtype=np.uint32)
+        cols = np.ascontiguousarray(code.cols, dtype=np.uint16)
+        coefs = np.ascontiguousarray(code.coefs, dtype=np.uint8)
+        return self._check(self._L.ldpc_amd_group_register_code(self._h, code.n, code.k, rp.ctypes.data, cols.ctypes.data, coefs.ctypes.data),
+                           "group_register_code")
+
+    def decode(self, code, sym, erased, max_sweeps=10, do_ml=1):
+        """Host arrays sym [F,n,S] or [F,n], erased [F,n] -> (out, sweeps, residual, status), frames sharded over the ranks."""
+        sym = np.ascontiguousarray(sym, dtype=np.uint8)
+        erased = np.ascontiguousarray(erased, dtype=np.uint8)
+        F = sym.shape[0]
+        S = 1 if sym.ndim == 2 else sym.shape[2]
+        out = np.empty_like(sym)
+        sw, res, st = (np.empty(F, dtype=np.int32) for _ in range(3))
+        self._check(self._L.ldpc_amd_group_decode_batch(self._h, code, S, F, sym.ctypes.data, erased.ctypes.data, max_sweeps, do_ml, out.ctypes.data,
+                                                        sw.ctypes.data, res.ctypes.data, st.ctypes.data), "group_decode_batch")
+        return out, sw, res, st
+
+    def decode_resident(self, code, S, nframes, sym, erased, out, words, gathered_words=None, gathered_out=None, max_sweeps=10, do_ml=1):
+        """Per-rank lists of torch CUDA tensors (rank r's shard on its device); gathered_*: tensors on rank 0's device or None.
+        Returns (decode_ms, gather_ms)."""
+        arr = lambda ts: (C.c_void_p * self.nranks)(*[t.data_ptr() if t is not None else None for t in ts])   # noqa: E731
+        dms, gms = C.c_double(0), C.c_double(0)
+        self._check(self._L.ldpc_amd_group_decode_resident(self._h, code, S, nframes, arr(sym), arr(erased), max_sweeps, do_ml, arr(out), arr(words),
+                                                           None if gathered_words is None else gathered_words.data_ptr(),
+                                                           None if gathered_out is None else gathered_out.data_ptr(), C.byref(dms), C.byref(gms)),
+                    "group_decode_resident")
+        return dms.value, gms.value
+
+    def fpga_run(self, nldpc, seed, per64, code_ind, num_frames, num_iter, perf_tests_body=False):
+        st = ErrorType()
+        self._check(self._L.ldpc_amd_group_fpga_run(self._h, nldpc, seed, per64, code_ind, num_frames, num_iter, int(perf_tests_body), C.byref(st)),
+                    "group_fpga_run")
+        return st.num_LDPC_errors, st.num_RS_errors
+
+    def bench_resident(self, code_ind, coef_seed, S, frames_per_rank, per=0.10, max_sweeps=10, steps=5):
+        r = (C.c_double * 4)()
+        self._check(self._L.ldpc_amd_group_bench_resident(self._h, code_ind, coef_seed, S, frames_per_rank, per, max_sweeps, steps, r), "group_bench_resident")
+        return dict(zip(("frames_per_s", "decode_ms_per_step", "gather_ms", "verified"), list(r)))

@@ -1226,16 +1226,23 @@ static const long kFpgaKeepFrames = 1l << 22;
 int ldpc_amd_data_in(ldpc_amd_ctx *ctx, const ldpc_amd_symbol_type *data_in, unsigned short nldpc, int seed,
                      int PER_numerator_div_64, int code_ind, long numFrames)
 {
+    return ldpc_amd_data_in_at(ctx, data_in, nldpc, seed, PER_numerator_div_64, code_ind, numFrames, 0);
+}
+
+int ldpc_amd_data_in_at(ldpc_amd_ctx *ctx, const ldpc_amd_symbol_type *data_in, unsigned short nldpc, int seed,
+                        int PER_numerator_div_64, int code_ind, long numFrames, long firstFrame)
+{
     (void)data_in;  // the FPGA kernel never reads its buffer either (ldpc_erasure_decoder_top.cl:84-117)
     if (!ctx) return LDPC_AMD_EINVAL;
     const BuiltinCode *b = find_builtin(code_ind);
     if (!b) return set_error(ctx, LDPC_AMD_ENOCODE, "no built-in code with index %d", code_ind);
-    if (numFrames < 0) return set_error(ctx, LDPC_AMD_EINVAL, "numFrames < 0");
+    if (numFrames < 0 || firstFrame < 0) return set_error(ctx, LDPC_AMD_EINVAL, "numFrames / firstFrame < 0");
     (void)nldpc;  // the kernel takes n from ldpc_params[code_ind] (ldpc_erasure_decoder_top.cl:70-71), nldpc is only printed
     // The FPGA source is a frame loop feeding a channel (:84-117): nothing is materialised.  The erasure stream is a pure
     // function of (seed, symbol index), so the source is only armed here and its symbols are drawn chunk by chunk inside
     // the decoder call, the way the decoder kernel pulls them from LDPC_DEC_DIN.
     ctx->fpga_frames = numFrames; ctx->fpga_code_ind = code_ind; ctx->fpga_per64 = PER_numerator_div_64; ctx->fpga_seed = seed;
+    ctx->fpga_first = firstFrame;
     ctx->fpga_decoded = -1; ctx->fpga_kept = false;
     return LDPC_AMD_OK;
 }
@@ -1271,7 +1278,7 @@ static int fpga_run(ldpc_amd_ctx *ctx, short num_iter, int code_ind, bool halves
         int32_t *res = keep ? res_base + f0 : res_base, *its = keep ? it_base + f0 : it_base;
         // erased iff (rv & 0x3F) < PER_numerator_div_64 (ldpc_erasure_decoder_top.cl:105), rv from threefry4x32 with key
         // {1, seed} and the running symbol counter (:74-75,96-98): the FPGA's own erasure stream for this seed
-        if ((rc = launch_synth_fpga(ctx, (uint32_t)ctx->fpga_seed, (uint64_t)f0 * (uint64_t)hc->n, (int64_t)cnt * hc->n, ctx->fpga_per64, flags)))
+        if ((rc = launch_synth_fpga(ctx, (uint32_t)ctx->fpga_seed, (uint64_t)(ctx->fpga_first + f0) * (uint64_t)hc->n, (int64_t)cnt * hc->n, ctx->fpga_per64, flags)))
             return rc;
         if (halves) {
             if ((rc = launch_fpga_halves(ctx, hc->dev, cnt, flags, num_iter, res, its))) return rc;

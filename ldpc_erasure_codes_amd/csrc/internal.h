@@ -180,6 +180,7 @@ struct ldpc_amd_ctx {
     // enough to keep them for ldpc_amd_fpga_frame_stats, else of one chunk).
     ldpc_amd::Scratch fpga_erased, fpga_stats;
     long fpga_frames = -1;        // numFrames of the last ldpc_amd_data_in, -1 = none
+    long fpga_first = 0;          // first frame of the run in the source's stream (ldpc_amd_data_in_at: a shard of a multi-device run)
     long fpga_decoded = -1;       // numFrames the last decoder call ran over, -1 = no decoder call since data_in
     bool fpga_kept = false;       // per-frame results of the whole run are in fpga_stats
     int fpga_code_ind = -1;

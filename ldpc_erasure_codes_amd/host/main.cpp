@@ -12,6 +12,11 @@
 //   verify_output()        main.cpp:413-425     same comparison over k symbols x 128 words, PASSED / FAILED!
 //   cleanup()              main.cpp:668-691     ldpc_amd_cleanup
 //   options -p -n -e -h -i -c   :157-170        same letters and meanings
+//   (none: the reference host opens device 0)   -g N: N ranks -- one context and one host thread per device (rank r on device
+//                                               r modulo the device count), the BLER run sharded over them with the library's C
+//                                               shard arithmetic, the counters summed; -b F adds a payload run (F frames of 1 KB
+//                                               packets per rank, decoded in place on the devices, status words gathered to
+//                                               device 0 by peer copies) -- include/ldpc_erasure_amd_multi.h
 //
 // Differences that are deliberate: (1) both -e and -h run the HIP backend (there is no emulator and no CPU
 // fallback); -e only selects the small functional run without the throughput loop.  (2) When the two Matlab test
@@ -28,6 +33,7 @@
 #include <vector>
 
 #include "../../include/ldpc_erasure_amd.h"
+#include "../../include/ldpc_erasure_amd_multi.h"
 
 #define EMULATION_PLAT 0
 #define HARDWARE_PLAT 1
@@ -53,6 +59,9 @@ static long numFrames = 1000000;  // main.cpp:100
 static int seed = 0;
 static int PER_numerator_div_64 = 0;
 static int code_ind = 0;
+static int numRanks = 1;          // -g: ranks (one context + one host thread each)
+static long benchFrames = 0;      // -b: frames per rank of the payload run (0: none)
+static ldpc_amd_group *group = NULL;
 
 static bool init_opencl();
 static void run();
@@ -80,7 +89,9 @@ static void usage()
            "  -e          Run in emulation mode (functional run only; still on the GPU)\n"
            "  -h          Run on hardware (MI355X)\n"
            "  -i <arg>    number of message-passing iterations\n"
-           "  -c <arg>    code type: 0 = (2000, 1000), 1 = (2040, 1530), 2 = (4000, 2000)\n");
+           "  -c <arg>    code type: 0 = (2000, 1000), 1 = (2040, 1530), 2 = (4000, 2000)\n"
+           "  -g <arg>    ranks: one context and one host thread per device (rank r on device r mod #devices); the run is sharded\n"
+           "  -b <arg>    with -h: also decode <arg> frames of 1 KB packets per rank (GF(256) code), gather the status words to device 0\n");
 }
 
 int main(int argc, char **argv)
@@ -97,6 +108,8 @@ int main(int argc, char **argv)
         else if (a == "-n") numFrames = atol(need("-n"));
         else if (a == "-c") code_ind = atoi(need("-c"));
         else if (a == "-i") numItr = (short)atoi(need("-i"));
+        else if (a == "-g") numRanks = atoi(need("-g"));
+        else if (a == "-b") benchFrames = atol(need("-b"));
         else if (a == "-e") ptype = EMULATION_PLAT;
         else if (a == "-h") ptype = HARDWARE_PLAT;
         else { fprintf(stderr, "Unknown option '%s'\n", a.c_str()); return 1; }
@@ -183,7 +196,18 @@ static int verify_output()
 static bool init_opencl()
 {
     printf("Initializing %s\n", ldpc_amd_version());
-    if (ldpc_amd_init(0, &ctx) != LDPC_AMD_OK) {
+    if (numRanks < 1) numRanks = 1;
+    if (numRanks > 1) {
+        // N life-cycles side by side (the reference opens one device, main.cpp:470-476); rank 0's context does the functional run
+        if (ldpc_amd_group_create(numRanks, NULL, &group) != LDPC_AMD_OK) {
+            printf("ERROR: Unable to initialise %d ranks: %s\n", numRanks, ldpc_amd_last_error(NULL));
+            return false;
+        }
+        ctx = ldpc_amd_group_ctx(group, 0);
+        printf("%d ranks on devices", numRanks);
+        for (int r = 0; r < numRanks; r++) printf(" %d", ldpc_amd_group_device(group, r));
+        printf("\n");
+    } else if (ldpc_amd_init(0, &ctx) != LDPC_AMD_OK) {
         printf("ERROR: Unable to initialise the MI355X backend: %s\n", ldpc_amd_last_error(NULL));
         return false;
     }
@@ -233,11 +257,26 @@ static void run()
         // ---- throughput / BLER run: the three kernels with the reference's argument lists
         printf("Launching for device %d (%d elements)\n", 1, n_LEN);
         const double t0 = now_s();
+        ldpc_amd_error_type st;
+        if (group) {
+            // the same three kernels on every rank, rank r over its block of the frame stream (shard arithmetic in the library);
+            // the final gather is the two counters per rank
+            if (ldpc_amd_group_fpga_run(group, (unsigned short)n_LEN, seed, PER_numerator_div_64, code_ind, numFrames, numItr, 0, &st) < 0) {
+                fprintf(stderr, "ERROR: sharded run: %s\n", ldpc_amd_group_last_error(group));
+                cleanup();
+                exit(1);
+            }
+            for (int r = 0; r < numRanks; r++) {
+                int64_t f0, cnt;
+                ldpc_amd_shard_frames(numFrames, numRanks, r, &f0, &cnt);
+                printf("  rank %d (device %d): frames [%lld, %lld)\n", r, ldpc_amd_group_device(group, r), (long long)f0, (long long)(f0 + cnt));
+            }
+        } else {
         checkError(ldpc_amd_data_in(ctx, NULL, (unsigned short)n_LEN, seed, PER_numerator_div_64, code_ind, numFrames),
                    "Failed to launch data_in");
         checkError(ldpc_amd_ldpc_erasure_decoder(ctx, numItr, code_ind), "Failed to launch K_LDPC_ERASURE_DECODER");
-        ldpc_amd_error_type st;
         checkError(ldpc_amd_data_out(ctx, NULL, code_ind, numFrames, &st), "Failed to launch kernel_write");
+        }
         const double t1 = now_s();
         int params[6];
         ldpc_amd_code_params(code_ind, params);
@@ -255,11 +294,32 @@ static void run()
         printf("Pattern-only run: %.0f frames/sec (BLER statistics; no payload moved, so no bits/sec figure)\n",
                (double)numFrames / (t1 - t0));
     }
+    if (ptype == HARDWARE_PLAT && benchFrames > 0) {
+        // ---- payload run, all in C: every rank decodes benchFrames frames of 1 KB packets resident on its device (weak scaling),
+        //      the status words are gathered to device 0 by peer copies
+        ldpc_amd_group *g = group;
+        if (!g && ldpc_amd_group_create(1, NULL, &g) != LDPC_AMD_OK) { fprintf(stderr, "ERROR: %s\n", ldpc_amd_last_error(NULL)); cleanup(); exit(1); }
+        double res[4] = {0, 0, 0, 0};
+        const int gf_seed[4] = {2000, 2040, 4000, 4080};
+        if (ldpc_amd_group_bench_resident(g, code_ind, (uint64_t)gf_seed[code_ind & 3], 1024, benchFrames, 0.10, 10, 10, res) < 0) {
+            fprintf(stderr, "ERROR: payload run: %s\n", ldpc_amd_group_last_error(g));
+            if (g != group) ldpc_amd_group_destroy(g);
+            cleanup();
+            exit(1);
+        }
+        printf("Payload run: %d rank(s) x %ld frames x %d symbols x 1024 B, uniform 10 %% erasures: %.0f frames/sec, %.3f ms per step, "
+               "gather of the status words to device 0: %.3f ms, %s\n", numRanks, benchFrames, n_LEN, res[0], res[1], res[2],
+               res[3] == 1.0 ? "every frame equals its codeword" : "MISMATCH");
+        printf("The throughput in information bits/sec: %.6e\n", res[0] * (double)k_LEN * 1024.0 * 8.0);
+        if (g != group) ldpc_amd_group_destroy(g);
+    }
     (void)start_time;
 }
 
 static void cleanup()
 {
-    if (ctx) ldpc_amd_cleanup(ctx);
+    if (group) ldpc_amd_group_destroy(group);   // (owns rank 0's context, which `ctx` aliases)
+    else if (ctx) ldpc_amd_cleanup(ctx);
+    group = NULL;
     ctx = NULL;
 }

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def header_symbols():
     syms = set()
-    for name in ("ldpc_erasure_amd.h", "ldpc_erasure_amd_wire.h"):   # every header under include/ that declares entry points
+    for name in ("ldpc_erasure_amd.h", "ldpc_erasure_amd_wire.h", "ldpc_erasure_amd_multi.h"):   # every header under include/ that declares entry points
         txt = open(os.path.join(ROOT, "include", name)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
         syms |= set(re.findall(r"\b(ldpc_amd_[a-z0-9_]+)\s*\(", txt))
