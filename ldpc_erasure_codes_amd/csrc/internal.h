@@ -46,6 +46,7 @@ struct DevCode {
     const uint8_t *ell_logc;  // [degpad][mpad]  log(coef)
     const uint8_t *ell_coef;  // [degpad][mpad]  coef
     const uint32_t *ell_pk;   // [degpad][mpad]  col | log(coef) << 16 (S = 1 kernel: one LDS read per neighbour)
+    const uint16_t *rx_off;   // [degpad][mpad]  col * 2, padding n * 2: byte offset of the neighbour's 16-bit key word (peel_relax.inc)
     const uint8_t *enc_invc;  // [m]  inverse of the coefficient each static encode step divides by
     const uint32_t *cell;     // [n][1 << cdw_shift]  column lists: check | coef << 16, 0xFFFFFFFF = none
     int cdw_shift;            // log2 of the padded column-list width (>= maxcoldeg)
@@ -108,6 +109,7 @@ struct Knobs {
     int scatter_t2b = 256;       // SCATTER_T2B: bytes of every row per TIER-2 workgroup (256: one workgroup per CU; 128: two)
     int peel_wpb = 0;            // PEEL_WPB: frames per peel workgroup (0 = auto)
     int peel_gt = -1;            // PEEL_GT: S = 1 kernel reads the code tables from global memory (-1 = auto)
+    int peel_relax = 1;          // PEEL_RELAX: S = 1 decode (and the pattern-only runs) by time-stamp relaxation (peel_relax.inc); 0: the serial per-solve loop
     int ml_solve = 1;            // ML_SOLVE: 1 solve schedules + solve kernel, 0 solve inside the ML kernel, 2 emit only (diagnostic)
     int ml_dbg = 0;              // ML_DBG: diagnostic build only
     int ml_solve_b = 128;        // ML_SOLVE_B: bytes of every row per solve-kernel workgroup

@@ -1316,6 +1316,9 @@ __global__ __launch_bounds__(1024, WPE) void ldpc_scatter_big_kernel(ScatterArgs
 
 #include "ml_kernel.inc"
 #include "ml_pi.inc"
+#define RELAX_LOG(i) c_log[i]
+#define RELAX_EXP(i) c_exp[i]
+#include "peel_relax.inc"
 
 // =================================================================================================
 // Synthetic inputs (role of the FPGA data_in kernel, OpenCL/device/ldpc_erasure_decoder_top.cl:57-120)
@@ -2073,6 +2076,86 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     pa.sweeps = d.sweeps; pa.residual = d.residual; pa.status = d.status; pa.residual_sys = d.residual_sys;
     pa.ml_list = (int32_t *)ctx->mllist.p; pa.ml_state = (uint8_t *)ctx->mlstate.p;
 
+    // ---- S = 1 decode and the pattern-only runs: exact time-stamp relaxation instead of the serial per-solve loop (peel_relax.inc)
+    //      when the keys fit 16 bits; the encoder's one-sweep chain and everything else keep ldpc_peel_kernel.
+    int logM = 0;
+    while ((1 << logM) < cd.mpad) logM++;
+    const bool relax_ok = kn.peel_relax != 0 && (fused || d.flags_only) && d.erased != nullptr && d.in_rows == cd.n && cd.degpad <= 16 &&
+                          cd.n <= 32767 && d.max_sweeps <= 62 && ((long)(d.max_sweeps + 1) << logM) <= 65535;
+    if (relax_ok) {
+        RelaxArgs ra{};
+        ra.n = cd.n; ra.k = cd.k; ra.m = cd.m; ra.mpad = cd.mpad; ra.logM = logM;
+        ra.rx_off = cd.rx_off; ra.ell_logc = cd.ell_logc;
+        ra.nframes = nf; ra.sym = d.sym; ra.erased = d.erased; ra.max_sweeps = d.max_sweeps; ra.do_ml = d.flags_only ? 0 : d.do_ml;
+        ra.out = d.out; ra.sweeps = d.sweeps; ra.residual = d.residual; ra.status = d.status; ra.residual_sys = d.residual_sys;
+        ra.ml_list = (int32_t *)ctx->mllist.p; ra.ml_state = (uint8_t *)ctx->mlstate.p;
+        // LDS plan: per frame its keys / values, solver and order lists; the code tables once per workgroup (or from global memory).
+        // Frames per CU = workgroups per CU x wavefronts per workgroup; the tables in LDS for short batches (a single round is
+        // latency bound), in global memory when the batch is deep and that puts >= 1.3x more frames on a CU (measured: (2040,1530)
+        // 59 -> 70 M frames/s, (4080,3060) 23 -> 27 M on 65536 frames; 4096 frames: 53 M with the LDS copy, 34 M without).
+        auto plan = [&](bool gt_, int w_, RelaxLds &Lr) {
+            int off = 0;
+            Lr.off16 = off; if (!gt_) off += align_up(2 * cd.degpad * cd.mpad, 16);
+            Lr.logc8 = off; if (!gt_) off += align_up(cd.degpad * cd.mpad, 16);
+            Lr.lg = off; off += 256;
+            Lr.ex = off; off += 512;
+            Lr.wave0 = off;
+            int w = 0;
+            Lr.key = w; w += align_up(2 * (cd.n + 1), 16);
+            Lr.fire = w; w += align_up(2 * cd.mpad, 16);
+            Lr.order = w; w += align_up(2 * cd.mpad, 16);
+            Lr.cnt = w; w += 256;
+            Lr.wave_stride = w;
+            Lr.total = off + w_ * w;
+        };
+        auto best_plan = [&](bool gt_, int &w_best, RelaxLds &L_best) -> int {
+            int best_f = 0;
+            const int wcap = kn.peel_wpb > 0 ? std::min(16, kn.peel_wpb) : 16;
+            for (int w_ = 1; w_ <= wcap; w_++) {
+                RelaxLds t;
+                plan(gt_, w_, t);
+                if (t.total > kLdsMax) break;
+                const int frames = kn.peel_wpb > 0 ? w_ : std::min(32, (kLdsMax / t.total) * w_);
+                if (frames >= best_f) { best_f = frames; w_best = w_; L_best = t; }
+            }
+            return best_f;
+        };
+        int w_l = 1, w_g = 1;
+        RelaxLds L_l{}, L_g{};
+        const int f_l = best_plan(false, w_l, L_l), f_g = best_plan(true, w_g, L_g);
+        if (f_l > 0 || f_g > 0) {
+            const bool deep = nf >= (int64_t)3 * std::max(f_l, 1) * ctx->sm_count;
+            const bool use_gt = kn.peel_gt == 1 || f_l == 0 || (kn.peel_gt != 0 && deep && f_g * 10 >= f_l * 13);
+            const int wr = use_gt ? w_g : w_l;
+            ra.lds = use_gt ? L_g : L_l;
+            ctx->last_plan[0] = wr; ctx->last_plan[1] = use_gt ? f_g : f_l; ctx->last_plan[2] = use_gt ? 1 : 0;
+            ctx->last_plan[3] = ra.lds.total; ctx->last_plan[4] = ra.lds.wave_stride;
+            const dim3 g((unsigned)((nf + wr - 1) / wr)), b((unsigned)(wr * 64));
+            char nm[96];
+            snprintf(nm, sizeof(nm), "ldpc_peel_relax_kernel<%d, %s, %s>", cd.degpad, use_gt ? "true" : "false", d.flags_only ? "true" : "false");
+            ctx->prof_names[LDPC_AMD_PROF_PEEL] = nm;
+            hipEvent_t ev = prof_begin(ctx);
+#define LDPC_RELAX_CASE(D, G, FO)                                                                                        \
+    if (cd.degpad == D && use_gt == G && (d.flags_only != 0) == FO) {                                                    \
+        auto kfn = ldpc_peel_relax_kernel<D, G, FO>;                                                                     \
+        LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(kfn)));                                           \
+        hipLaunchKernelGGL(kfn, g, b, (size_t)ra.lds.total, ctx->stream, ra);                                            \
+    }
+            LDPC_RELAX_CASE(8, false, false) LDPC_RELAX_CASE(8, true, false) LDPC_RELAX_CASE(8, false, true) LDPC_RELAX_CASE(8, true, true)
+            LDPC_RELAX_CASE(14, false, false) LDPC_RELAX_CASE(14, true, false) LDPC_RELAX_CASE(14, false, true) LDPC_RELAX_CASE(14, true, true)
+            LDPC_RELAX_CASE(16, false, false) LDPC_RELAX_CASE(16, true, false) LDPC_RELAX_CASE(16, false, true) LDPC_RELAX_CASE(16, true, true)
+#undef LDPC_RELAX_CASE
+            LDPC_HIP_TRY(ctx, hipGetLastError());
+            prof_end(ctx, LDPC_AMD_PROF_PEEL, ev);
+            if (d.flags_only) return LDPC_AMD_OK;
+            if (d.do_ml) {
+                if ((rc = ml_prepare())) return rc;
+                if ((rc = ml_front())) return rc;
+                if ((rc = ml_back())) return rc;
+            }
+            return LDPC_AMD_OK;
+        }
+    }
     if (d.flags_only) {
         LDPC_HIP_TRY(ctx, launch_peel_t<false>(pa, wpb, ctx->stream));
         return LDPC_AMD_OK;

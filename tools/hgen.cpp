@@ -58,7 +58,11 @@ static std::vector<int> parse_profile(const char *s)
 
 int main(int argc, char **argv)
 {
-    if (argc != 7) { fprintf(stderr, "usage: hgen n k rowprofile colprofile seed out.csr.bin\n"); return 1; }
+    if (argc != 7 && argc != 8) { fprintf(stderr, "usage: hgen n k rowprofile colprofile seed out.csr.bin [strict-tries]\n"); return 1; }
+    // strict-tries > 0: the reference's own rule (Hgen_irregular...m:94-203) -- column budgets are never relaxed before the last
+    // 0.3 % of the rows (:113-115), a row that cannot be completed aborts the attempt and the whole matrix is started again with
+    // the next seed, up to strict-tries attempts; the best attempt's progress is reported when none succeeds.
+    const int strict_tries = argc == 8 ? atoi(argv[7]) : 0;
     const int n = atoi(argv[1]), k = atoi(argv[2]), m = n - k;
     std::vector<int> rowdeg = parse_profile(argv[3]), tgt = parse_profile(argv[4]);
     rng_state = strtoull(argv[5], nullptr, 10);
@@ -67,6 +71,14 @@ int main(int argc, char **argv)
     std::vector<std::vector<int>> rows(m), cols(n);
     std::vector<int> cur(n, 0), mark(n, -1);
     int stamp = 0, relaxed_rows = 0, short_rows = 0;
+    int attempt = 0, best_row = -1;
+    const uint64_t seed0 = rng_state;
+restart:
+    for (auto &r : rows) r.clear();
+    for (auto &c : cols) c.clear();
+    std::fill(cur.begin(), cur.end(), 0);
+    relaxed_rows = short_rows = 0;
+    rng_state = seed0 + 0x1000003ull * (uint64_t)attempt;
 
     auto closes_short_cycle = [&](int i, int v) -> bool {
         // columns already in row i
@@ -101,6 +113,12 @@ int main(int argc, char **argv)
                 if (left > 0 && !tried[c]) { avail.push_back(c); total += (double)left * left * left; }
             }
             if (avail.empty()) {
+                if (strict_tries > 0 && (double)(i + 1) / m <= 0.997) {   // reference: ok = 0 -> a new attempt (:176-178,199-203)
+                    best_row = std::max(best_row, i);
+                    if (++attempt < strict_tries) goto restart;
+                    fprintf(stderr, "strict mode: no attempt of %d completed; the best one got to row %d of %d\n", strict_tries, best_row, m);
+                    return 5;
+                }
                 if (relax >= 4) { short_rows++; break; }  // accept a lighter row rather than restarting (reference: restart)
                 relax++;
                 std::fill(tried.begin(), tried.end(), 0);
@@ -157,6 +175,7 @@ int main(int argc, char **argv)
     fwrite(row_ptr.data(), 4, row_ptr.size(), f);
     fwrite(cc.data(), 2, cc.size(), f);
     fclose(f);
+    if (strict_tries > 0) printf("strict mode: attempt %d of %d completed\n", attempt + 1, strict_tries);
     printf("n=%d k=%d m=%d nnz=%zu max row degree %d, max column degree %d, %d staircase ones, %d rows needed a relaxed budget, %d rows left lighter\n",
            n, k, m, cc.size(), maxrow, maxcol, staircase, relaxed_rows, short_rows);
     return 0;
