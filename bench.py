@@ -52,7 +52,7 @@ SEED_SRC, SEED_ERA = 20261004, 20261005
 GE_PARAMS = (0.13, 0.8, 10.0)   # cfg 3: alpha, beta, good_transition_bias -- ML stage on ~28 % of the frames
 # PMC summaries (separate rocprofv3 --pmc passes of this same command, committed): newest first
 PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in
-                 ("round3_pmc_summary.json", "round3_cfg4p_pmc_summary.json", "round2_pmc_summary.json")]
+                 ("round4_pmc_summary.json", "round4_cfg4p_pmc_summary.json", "round3_pmc_summary.json", "round3_cfg4p_pmc_summary.json", "round2_pmc_summary.json")]
 
 # BASELINE.json configs -> (code_ind, channel, frames)
 WORKLOADS = {
