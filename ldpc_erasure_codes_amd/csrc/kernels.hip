@@ -808,14 +808,22 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     }
     for (int s = tid + SPT * nthr; s < nsteps; s += nthr) put_step(s, gs[s], gic[s]);
     if (lds_lists) {
+        // The lists go to LDS TRANSLATED (check -> LDS address of the step's accumulator slice | coef << 24, the form the turns of
+        // `scatter` consume; the list's own step left out): the two dependent look-ups of the translation then happen once, here,
+        // for all steps at a time, instead of inside every level's chain of LDS round trips (round 4).
+        __syncthreads();   // the check -> slot table is complete
+        auto xl = [&](uint32_t w, uint32_t own) -> uint32_t {
+            const uint32_t s_ = soc[w == 0xFFFFFFFFu ? 0u : (w & 0xFFFFu)];
+            return (w != 0xFFFFFFFFu && s_ != 0xFFFFu && s_ != own) ? (((uint32_t)kAccOff + s_ * (uint32_t)B) | ((w & 0x00FF0000u) << 8)) : 0xFFFFFFFFu;
+        };
 #pragma unroll
         for (int u = 0; u < LPT; u++) {
             const int e = tid + u * nthr;
-            if (e < nsteps * cdw) slist[e] = lw[u];
+            if (e < nsteps * cdw) slist[e] = xl(lw[u], (uint32_t)(e / cdw));
         }
         for (int e = tid + LPT * nthr; e < nsteps * cdw; e += nthr) {
             const int s = e / cdw, idx = e - s * cdw;
-            slist[e] = cd.cell[((int64_t)(gs[s] >> 16) << cd.cdw_shift) + idx];
+            slist[e] = xl(cd.cell[((int64_t)(gs[s] >> 16) << cd.cdw_shift) + idx], (uint32_t)s);
         }
     }
     __syncthreads();
@@ -1201,7 +1209,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
                     val = gfmul16(lds_multab(mt, invc[s]), a16);
                     stream_store16<NT>(out_row(t), val);
                 }
-                to_slots(ew, (s < s1) ? (uint32_t)s : 0xFFFFu);
+                if (MODE != 1) to_slots(ew, (s < s1) ? (uint32_t)s : 0xFFFFu);   // (MODE 1: translated at set-up)
                 scatter(val, ew);
             }
             if (!LL && L < nlev) load_list((int)lvlend[L] + wave * RPW + g, (int)lvlend[L + 1], ewn);
