@@ -87,6 +87,7 @@ static const KnobDesc kKnobs[] = {
     LDPC_KNOB_INT("SCATTER_R", scatter_r, x == 1 || x == 2 || x == 4),
     LDPC_KNOB_INT("SCATTER_R2", scatter_r2, x >= 2 && x <= 4),
     LDPC_KNOB_INT("SCATTER_T2B", scatter_t2b, x == 256 || x == 128),
+    LDPC_KNOB_INT("SCATTER_XL", scatter_xl, x == 0 || x == 1),
     LDPC_KNOB_INT("PEEL_WPB", peel_wpb, x >= 0 && x <= 16),
     LDPC_KNOB_INT("PEEL_GT", peel_gt, x >= -1 && x <= 1),
     LDPC_KNOB_INT("PEEL_RELAX", peel_relax, x == 0 || x == 1),

@@ -106,6 +106,7 @@ struct Knobs {
     int scatter_dyn = 1;         // SCATTER_DYN: 1 LDS counter, 0 fixed stride, 2 compacted list, 3 sorted list, 4 list sorted inside 64-row windows
     int scatter_r = 2;           // SCATTER_R: row pieces in flight per lane group, tier 1 (1, 2, 4)
     int scatter_r2 = 3;          // SCATTER_R2: ... tier 2 (2, 3, 4)
+    int scatter_xl = 1;          // SCATTER_XL: the level phase's lists are translated to accumulator addresses at set-up (0: inside every level)
     int scatter_t2b = 256;       // SCATTER_T2B: bytes of every row per TIER-2 workgroup (256: one workgroup per CU; 128: two)
     int peel_wpb = 0;            // PEEL_WPB: frames per peel workgroup (0 = auto)
     int peel_gt = -1;            // PEEL_GT: S = 1 kernel reads the code tables from global memory (-1 = auto)

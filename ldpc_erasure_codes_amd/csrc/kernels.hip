@@ -609,6 +609,7 @@ struct ScatterArgs {
     int lds_soc_bytes;        // size of the row-kind / row-list region
     int enc_list;             // encode: stream the source rows in DevCode::enc_order
     int enc_clist;            // encode: the level phase reads DevCode::enc_lst from LDS (copied over the dead row tables at lds_soc)
+    int xl_setup;             // level-phase lists translated (check -> accumulator address) at set-up instead of inside every level
     int enc_group;            // encode: the grouped static schedule (DevCode::encg_*: levels collapsed offline, steps pull in-group accumulators)
     int *err;                 // pinned host word (ldpc_amd_ctx::dev_err_host): a kernel whose assumptions do not hold reports here
     int dbg;                  // diagnostic build only (-DLDPC_AMD_MLDBG): 32768 = tier 1 also takes the frames with more than tcap steps,
@@ -811,8 +812,9 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         // The lists go to LDS TRANSLATED (check -> LDS address of the step's accumulator slice | coef << 24, the form the turns of
         // `scatter` consume; the list's own step left out): the two dependent look-ups of the translation then happen once, here,
         // for all steps at a time, instead of inside every level's chain of LDS round trips (round 4).
-        __syncthreads();   // the check -> slot table is complete
+        if (a.xl_setup) __syncthreads();   // the check -> slot table is complete
         auto xl = [&](uint32_t w, uint32_t own) -> uint32_t {
+            if (!a.xl_setup) return w;
             const uint32_t s_ = soc[w == 0xFFFFFFFFu ? 0u : (w & 0xFFFFu)];
             return (w != 0xFFFFFFFFu && s_ != 0xFFFFu && s_ != own) ? (((uint32_t)kAccOff + s_ * (uint32_t)B) | ((w & 0x00FF0000u) << 8)) : 0xFFFFFFFFu;
         };
@@ -1209,7 +1211,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
                     val = gfmul16(lds_multab(mt, invc[s]), a16);
                     stream_store16<NT>(out_row(t), val);
                 }
-                if (MODE != 1) to_slots(ew, (s < s1) ? (uint32_t)s : 0xFFFFu);   // (MODE 1: translated at set-up)
+                if (MODE != 1 || !a.xl_setup) to_slots(ew, (s < s1) ? (uint32_t)s : 0xFFFFu);   // (MODE 1: translated at set-up)
                 scatter(val, ew);
             }
             if (!LL && L < nlev) load_list((int)lvlend[L] + wave * RPW + g, (int)lvlend[L + 1], ewn);
@@ -2084,27 +2086,31 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     pa.sweeps = d.sweeps; pa.residual = d.residual; pa.status = d.status; pa.residual_sys = d.residual_sys;
     pa.ml_list = (int32_t *)ctx->mllist.p; pa.ml_state = (uint8_t *)ctx->mlstate.p;
 
-    // ---- S = 1 decode and the pattern-only runs: exact time-stamp relaxation instead of the serial per-solve loop (peel_relax.inc)
-    //      when the keys fit 16 bits; the encoder's one-sweep chain and everything else keep ldpc_peel_kernel.
+    // ---- exact time-stamp relaxation instead of the serial per-solve loop (peel_relax.inc) when the keys fit 16 bits: S = 1 decode
+    //      (mode 0), the pattern-only runs (mode 1), the packet path's schedules (mode 2).  The encoder's one-sweep chain and
+    //      everything else keep ldpc_peel_kernel.  Returns 1: launched, 0: not applicable, < 0: error.
     int logM = 0;
     while ((1 << logM) < cd.mpad) logM++;
-    const bool relax_ok = kn.peel_relax != 0 && (fused || d.flags_only) && d.erased != nullptr && d.in_rows == cd.n && cd.degpad <= 16 &&
-                          cd.n <= 32767 && d.max_sweeps <= 62 && ((long)(d.max_sweeps + 1) << logM) <= 65535;
-    if (relax_ok) {
+    const bool relax_ok = kn.peel_relax != 0 && d.erased != nullptr && d.in_rows == cd.n && cd.degpad <= 16 && cd.n <= 32767 &&
+                          d.max_sweeps <= 62 && ((long)(d.max_sweeps + 1) << logM) <= 65535;
+    auto relax_launch = [&](int mode) -> int {
+        if (!relax_ok) return 0;
         RelaxArgs ra{};
         ra.n = cd.n; ra.k = cd.k; ra.m = cd.m; ra.mpad = cd.mpad; ra.logM = logM;
-        ra.rx_off = cd.rx_off; ra.ell_logc = cd.ell_logc;
-        ra.nframes = nf; ra.sym = d.sym; ra.erased = d.erased; ra.max_sweeps = d.max_sweeps; ra.do_ml = d.flags_only ? 0 : d.do_ml;
+        ra.rx_off = cd.rx_off; ra.ell_logc = cd.ell_logc; ra.ell_coef = cd.ell_coef;
+        ra.nframes = nf; ra.sym = d.sym; ra.erased = d.erased; ra.max_sweeps = d.max_sweeps; ra.do_ml = mode == 1 ? 0 : d.do_ml;
         ra.out = d.out; ra.sweeps = d.sweeps; ra.residual = d.residual; ra.status = d.status; ra.residual_sys = d.residual_sys;
         ra.ml_list = (int32_t *)ctx->mllist.p; ra.ml_state = (uint8_t *)ctx->mlstate.p;
-        // LDS plan: per frame its keys / values, solver and order lists; the code tables once per workgroup (or from global memory).
-        // Frames per CU = workgroups per CU x wavefronts per workgroup; the tables in LDS for short batches (a single round is
-        // latency bound), in global memory when the batch is deep and that puts >= 1.3x more frames on a CU (measured: (2040,1530)
-        // 59 -> 70 M frames/s, (4080,3060) 23 -> 27 M on 65536 frames; 4096 frames: 53 M with the LDS copy, 34 M without).
+        ra.sched_hdr = pa.sched_hdr; ra.sched_steps = pa.sched_steps; ra.sched_lvlend = pa.sched_lvlend; ra.sched_invc = pa.sched_invc;
+        ra.big_list = pa.big_list; ra.tcap = pa.tcap;
+        // LDS plan: per frame its keys / values, solver and order lists (packets: + the level histogram); the code tables once per
+        // workgroup (or from global memory).  Frames per CU = workgroups per CU x wavefronts per workgroup; the tables in LDS for short
+        // batches (a single round is latency bound), in global memory when the batch is deep and that puts >= 1.3x more frames on a CU
+        // (measured: (2040,1530) 59 -> 70 M frames/s, (4080,3060) 23 -> 27 M on 65536 frames; 4096 frames: 53 M with the LDS copy, 34 M without).
         auto plan = [&](bool gt_, int w_, RelaxLds &Lr) {
             int off = 0;
             Lr.off16 = off; if (!gt_) off += align_up(2 * cd.degpad * cd.mpad, 16);
-            Lr.logc8 = off; if (!gt_) off += align_up(cd.degpad * cd.mpad, 16);
+            Lr.logc8 = off; if (!gt_ && mode == 0) off += align_up(cd.degpad * cd.mpad, 16);
             Lr.lg = off; off += 256;
             Lr.ex = off; off += 512;
             Lr.wave0 = off;
@@ -2113,6 +2119,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             Lr.fire = w; w += align_up(2 * cd.mpad, 16);
             Lr.order = w; w += align_up(2 * cd.mpad, 16);
             Lr.cnt = w; w += 256;
+            Lr.hist = w; if (mode == 2) w += align_up(4 * (cd.m + 2), 16);
             Lr.wave_stride = w;
             Lr.total = off + w_ * w;
         };
@@ -2131,30 +2138,40 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         int w_l = 1, w_g = 1;
         RelaxLds L_l{}, L_g{};
         const int f_l = best_plan(false, w_l, L_l), f_g = best_plan(true, w_g, L_g);
-        if (f_l > 0 || f_g > 0) {
-            const bool deep = nf >= (int64_t)3 * std::max(f_l, 1) * ctx->sm_count;
-            const bool use_gt = kn.peel_gt == 1 || f_l == 0 || (kn.peel_gt != 0 && deep && f_g * 10 >= f_l * 13);
-            const int wr = use_gt ? w_g : w_l;
-            ra.lds = use_gt ? L_g : L_l;
-            ctx->last_plan[0] = wr; ctx->last_plan[1] = use_gt ? f_g : f_l; ctx->last_plan[2] = use_gt ? 1 : 0;
-            ctx->last_plan[3] = ra.lds.total; ctx->last_plan[4] = ra.lds.wave_stride;
-            const dim3 g((unsigned)((nf + wr - 1) / wr)), b((unsigned)(wr * 64));
-            char nm[96];
-            snprintf(nm, sizeof(nm), "ldpc_peel_relax_kernel<%d, %s, %s>", cd.degpad, use_gt ? "true" : "false", d.flags_only ? "true" : "false");
-            ctx->prof_names[LDPC_AMD_PROF_PEEL] = nm;
-            hipEvent_t ev = prof_begin(ctx);
-#define LDPC_RELAX_CASE(D, G, FO)                                                                                        \
-    if (cd.degpad == D && use_gt == G && (d.flags_only != 0) == FO) {                                                    \
-        auto kfn = ldpc_peel_relax_kernel<D, G, FO>;                                                                     \
+        if (f_l <= 0 && f_g <= 0) return 0;
+        const bool deep = nf >= (int64_t)3 * std::max(f_l, 1) * ctx->sm_count;
+        const bool use_gt = kn.peel_gt == 1 || f_l == 0 || (kn.peel_gt != 0 && deep && f_g * 10 >= f_l * 13);
+        const int wr = use_gt ? w_g : w_l;
+        ra.lds = use_gt ? L_g : L_l;
+        ctx->last_plan[0] = wr; ctx->last_plan[1] = use_gt ? f_g : f_l; ctx->last_plan[2] = use_gt ? 1 : 0;
+        ctx->last_plan[3] = ra.lds.total; ctx->last_plan[4] = ra.lds.wave_stride;
+        const dim3 g((unsigned)((nf + wr - 1) / wr)), b((unsigned)(wr * 64));
+        char nm[96];
+        snprintf(nm, sizeof(nm), "ldpc_peel_relax_kernel<%d, %s, %d>", cd.degpad, use_gt ? "true" : "false", mode);
+        ctx->prof_names[LDPC_AMD_PROF_PEEL] = nm;
+        hipEvent_t ev = prof_begin(ctx);
+        bool launched = false;
+#define LDPC_RELAX_CASE(D, G, MD)                                                                                        \
+    if (!launched && cd.degpad == D && use_gt == G && mode == MD) {                                                      \
+        auto kfn = ldpc_peel_relax_kernel<D, G, MD>;                                                                     \
         LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(kfn)));                                           \
         hipLaunchKernelGGL(kfn, g, b, (size_t)ra.lds.total, ctx->stream, ra);                                            \
+        launched = true;                                                                                                 \
     }
-            LDPC_RELAX_CASE(8, false, false) LDPC_RELAX_CASE(8, true, false) LDPC_RELAX_CASE(8, false, true) LDPC_RELAX_CASE(8, true, true)
-            LDPC_RELAX_CASE(14, false, false) LDPC_RELAX_CASE(14, true, false) LDPC_RELAX_CASE(14, false, true) LDPC_RELAX_CASE(14, true, true)
-            LDPC_RELAX_CASE(16, false, false) LDPC_RELAX_CASE(16, true, false) LDPC_RELAX_CASE(16, false, true) LDPC_RELAX_CASE(16, true, true)
+#define LDPC_RELAX_DEG(D)                                                                                                \
+    LDPC_RELAX_CASE(D, false, 0) LDPC_RELAX_CASE(D, true, 0) LDPC_RELAX_CASE(D, false, 1) LDPC_RELAX_CASE(D, true, 1)    \
+    LDPC_RELAX_CASE(D, false, 2) LDPC_RELAX_CASE(D, true, 2)
+        LDPC_RELAX_DEG(8) LDPC_RELAX_DEG(14) LDPC_RELAX_DEG(16)
+#undef LDPC_RELAX_DEG
 #undef LDPC_RELAX_CASE
-            LDPC_HIP_TRY(ctx, hipGetLastError());
-            prof_end(ctx, LDPC_AMD_PROF_PEEL, ev);
+        LDPC_HIP_TRY(ctx, hipGetLastError());
+        prof_end(ctx, LDPC_AMD_PROF_PEEL, ev);
+        return launched ? 1 : 0;
+    };
+    if (fused || d.flags_only) {
+        const int rl = relax_launch(d.flags_only ? 1 : 0);
+        if (rl < 0) return rl;
+        if (rl > 0) {
             if (d.flags_only) return LDPC_AMD_OK;
             if (d.do_ml) {
                 if ((rc = ml_prepare())) return rc;
@@ -2189,9 +2206,14 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             pa.tcap = plan.tcap;
             pa.big_list = plan.two_tier ? (int32_t *)ctx->biglist.p : nullptr;
         }
-        hipEvent_t ev = prof_begin(ctx);
-        LDPC_HIP_TRY(ctx, launch_peel_t<false>(pa, wpb, ctx->stream));
-        prof_end(ctx, LDPC_AMD_PROF_PEEL, ev);
+        hipEvent_t ev = nullptr;
+        const int rl = relax_launch(2);   // the schedules by relaxation when its keys fit (else, and with PEEL_RELAX=0: the serial loop)
+        if (rl < 0) return rl;
+        if (rl == 0) {
+            ev = prof_begin(ctx);
+            LDPC_HIP_TRY(ctx, launch_peel_t<false>(pa, wpb, ctx->stream));
+            prof_end(ctx, LDPC_AMD_PROF_PEEL, ev);
+        }
 
         if (d.do_ml) {
             if ((rc = ml_prepare())) return rc;
@@ -2205,7 +2227,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             ScatterArgs sa{};
             sa.code = cd; sa.S = d.S; sa.nslices = plan.nslices; sa.nframes = nf; sa.sym = d.sym; sa.erased = d.erased; sa.out = d.out;
             sa.in_rows = cd.n; sa.static_sched = 0; sa.inplace = d.inplace;
-            sa.dbg = kn.ml_dbg; sa.err = ctx->dev_err_host;
+            sa.dbg = kn.ml_dbg; sa.err = ctx->dev_err_host; sa.xl_setup = kn.scatter_xl;
             sa.sched_hdr = pa.sched_hdr; sa.sched_steps = pa.sched_steps; sa.sched_lvlend = pa.sched_lvlend;
             sa.sched_invc = pa.sched_invc;
             ev = prof_begin(ctx);

@@ -18,6 +18,8 @@ KNOBS = [
     ("LDPC_AMD_SCATTER_B", ["128", "64"]),
     ("LDPC_AMD_SCATTER_R", ["1", "4"]),
     ("LDPC_AMD_SCATTER_R2", ["2", "4"]),
+    ("LDPC_AMD_SCATTER_T2B", ["128"]),
+    ("LDPC_AMD_SCATTER_XL", ["0"]),
     ("LDPC_AMD_SCATTER_NT", ["0"]),
     ("LDPC_AMD_SCATTER_XCD", ["0"]),
     ("LDPC_AMD_SCATTER_DYN", ["0", "2", "3", "4"]),

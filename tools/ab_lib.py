@@ -38,7 +38,8 @@ def child(so):
     cw, sym, era, _ = g.make_batch("cfg2", 1, 1024, frame0=0, nframes=4096)
     out = torch.empty_like(sym)
     st = torch.empty(sym.shape[0], dtype=torch.int32, device=g.dev)
-    res["cfg2_apply"] = timed(lambda: ctx.decode(h, sym, era, out=out, status=st), ["apply"])["apply"]
+    t2 = timed(lambda: ctx.decode(h, sym, era, out=out, status=st), ["peel", "apply"])
+    res["cfg2_apply"], res["cfg2_peel"] = t2["apply"], t2["peel"]
     assert torch.equal(out, cw)
     src = cw[:, :k, :].contiguous()
     enc = torch.empty_like(cw)
@@ -57,7 +58,7 @@ def child(so):
     out = torch.empty_like(sym)
     st = torch.empty(sym.shape[0], dtype=torch.int32, device=g.dev)
     t = timed(lambda: ctx.decode(h, sym, era, out=out, status=st), ["peel", "apply", "ml"])
-    res["cfg3_apply"], res["cfg3_ml"] = t["apply"], t["ml"]
+    res["cfg3_apply"], res["cfg3_ml"], res["cfg3_peel"] = t["apply"], t["ml"], t["peel"]
     ok = st.cpu().numpy() <= 1
     assert torch.equal(out[torch.from_numpy(ok).to(g.dev)], cw[torch.from_numpy(ok).to(g.dev)])
     del cw, sym, era, out

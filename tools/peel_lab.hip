@@ -19,6 +19,7 @@
 #define RELAX_LAB 1
 #define RELAX_LOG(i) a.glog[i]
 #define RELAX_EXP(i) a.gexp[i]
+__constant__ unsigned char c_inv[256];   // (only the packet-schedule mode of the kernel file reads it; the lab runs MODE 0)
 
 namespace {
 struct alignas(16) U4 { uint32_t x, y, z, w; };
@@ -200,8 +201,8 @@ int main(int argc, char **argv)
         const int grid = (F + wpb - 1) / wpb;
 #define LAB_CASE(D, G, UU)                                                                                                   \
     if (degpad == D && gt == G && U == UU) {                                                                                 \
-        CK(hipFuncSetAttribute((const void *)ldpc_peel_relax_kernel<D, G != 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-        hipLaunchKernelGGL((ldpc_peel_relax_kernel<D, G != 0, false>), dim3(grid), dim3(wpb * 64), (size_t)L.total, 0, a);      \
+        CK(hipFuncSetAttribute((const void *)ldpc_peel_relax_kernel<D, G != 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+        hipLaunchKernelGGL((ldpc_peel_relax_kernel<D, G != 0, 0>), dim3(grid), dim3(wpb * 64), (size_t)L.total, 0, a);      \
     }
         LAB_CASE(8, 0, 1) LAB_CASE(8, 1, 1) LAB_CASE(14, 0, 1) LAB_CASE(14, 1, 1) LAB_CASE(16, 0, 1) LAB_CASE(16, 1, 1)
 #undef LAB_CASE
