@@ -5,6 +5,8 @@
   (a) level-split tier 2: the frames with more than tcap steps in two passes of tier-1 geometry (two workgroups per CU).  Bit 32768
       lets the tier-1 launch take those frames cut off at tcap steps and drops the tier-2 launch: that IS the first pass (all rows
       streamed and written once, <= tcap accumulators); the second pass (re-stream the rows the later steps consume) comes on top.
+  (c) (round 4) chain composition in the solve schedules: bits 4096 / 8192 leave out the barrier behind all but every second / fourth level of
+      the solve kernel -- what a schedule with half / a quarter of the levels could gain at most (the ops stay).
   (b) right-hand sides of the ML systems built inside the packet stream: bit 16384 skips level 0 of the solve kernel (the known-row
       re-read and its multiply-accumulates) -- the most (b) could remove, before the cost of doing the same products in the packet
       kernel and of moving the finished right-hand sides through HBM.
@@ -21,8 +23,9 @@ sys.path.insert(0, ROOT)
 
 
 def main():
-    so = sys.argv[1] if len(sys.argv) > 1 else "/tmp/libldpc_erasure_amd_mldbg.so"
-    if len(sys.argv) <= 1:
+    pre = os.path.join(ROOT, "tools", "bin", "libldpc_erasure_amd_mldbg.so")   # prebuilt: EXTRA_HIPCC_FLAGS=-DLDPC_AMD_MLDBG LDPC_AMD_OUT=... build.sh
+    so = sys.argv[1] if len(sys.argv) > 1 else (pre if os.path.exists(pre) else "/tmp/libldpc_erasure_amd_mldbg.so")
+    if len(sys.argv) <= 1 and so != pre:
         src = os.path.join(ROOT, "ldpc_erasure_codes_amd", "csrc")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-strict-aliasing", "-DLDPC_AMD_MLDBG",
                                "-shared", "-o", so, os.path.join(src, "kernels.hip"), os.path.join(src, "api.cpp"), os.path.join(src, "wire.cpp")])
@@ -42,8 +45,14 @@ def main():
     nst = None
     res = {}
     for rnd in range(5):
-        for name, dbg in (("product path", 0), ("(a) tier 1 takes every frame, cut off at tcap steps; no tier 2", 32768), ("(b) solve kernel without level 0", 16384)):
-            ctx.configure("ML_DBG", dbg)
+        for name, dbg in (("product path", 0), ("(a) tier 1 takes every frame, cut off at tcap steps; no tier 2", 32768), ("(b) solve kernel without level 0", 16384),
+                          ("fast path without its consistency test (ML_PI=2)", -2),
+                          ("(c) ML_PI=2, solve kernel: barrier behind every second level only", 4096), ("(c) ML_PI=2, ... behind every fourth level only", 8192),
+                          ("(c) ML_PI=2, every forward / backward op as ONE level", 256)):
+            # (the (c) runs produce wrong bytes, which the consistency test of the default mode would flag and redo: they run without it,
+            # next to a baseline without it)
+            ctx.configure("ML_PI", "2" if dbg in (-2, 4096, 8192, 256) else None)
+            ctx.configure("ML_DBG", max(dbg, 0))
             ctx.get_profile(); ctx.set_profiling(True)
             ctx.decode(h, sym, era, out=out, status=st)
             ctx.set_profiling(False)
@@ -54,6 +63,7 @@ def main():
                 ok = st <= 1
                 assert torch.equal(out[ok], cw[ok])
     ctx.configure("ML_DBG", None)
+    ctx.configure("ML_PI", None)
     print(f"cfg 3, S = 1024, {sym.shape[0]} frames; ms per step (median of 4): peel / packet kernels / ML stage (factor + solve)")
     for name, v in res.items():
         print(f"  {name:70s} {statistics.median(x[0] for x in v):.3f} / {statistics.median(x[1] for x in v):.3f} / {statistics.median(x[2] for x in v):.3f}")
