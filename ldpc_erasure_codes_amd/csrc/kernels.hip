@@ -509,7 +509,7 @@ __global__ __launch_bounds__(512) void ldpc_apply_kernel(ApplyArgs a)
     int nsteps, nlev;
     if (a.sched_hdr) {
         nsteps = (int)a.sched_hdr[2 * f];
-        nlev = (int)a.sched_hdr[2 * f + 1];
+        nlev = (int)(a.sched_hdr[2 * f + 1] & 0x7FFFFFFFu);
         const uint32_t *gs = a.sched_steps + f * m;
         const uint16_t *gl = a.sched_lvlend + f * (m + 1);
         for (int i = (int)threadIdx.x; i < nsteps; i += (int)blockDim.x) steps[i] = gs[i];
@@ -609,6 +609,8 @@ struct ScatterArgs {
     int lds_soc_bytes;        // size of the row-kind / row-list region
     int enc_list;             // encode: stream the source rows in DevCode::enc_order
     int enc_clist;            // encode: the level phase reads DevCode::enc_lst from LDS (copied over the dead row tables at lds_soc)
+    const uint32_t *sched_pull;   // [nframes][m][4] pairs: level of the step, two pulled accumulators (slot | coef << 24), spare (peel_relax.inc mode 2)
+    int pairs;                // the schedules' levels come in groups of two (first / second half): one barrier per group, second halves pull
     int xl_setup;             // level-phase lists translated (check -> accumulator address) at set-up instead of inside every level
     int enc_group;            // encode: the grouped static schedule (DevCode::encg_*: levels collapsed offline, steps pull in-group accumulators)
     int *err;                 // pinned host word (ldpc_amd_ctx::dev_err_host): a kernel whose assumptions do not hold reports here
@@ -737,7 +739,8 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     const int nsteps = a.static_sched ? cd.m : (int)a.sched_hdr[2 * f];
 #endif
     const bool grouped = a.static_sched && a.enc_group;
-    const int nlev = a.static_sched ? (grouped ? cd.encg_nlevels : cd.enc_nlevels) : (int)a.sched_hdr[2 * f + 1];
+    const uint32_t hdr1 = a.static_sched ? 0u : a.sched_hdr[2 * f + 1];   // levels | bit 31: they come in pairs (peel_relax.inc mode 2)
+    const int nlev = a.static_sched ? (grouped ? cd.encg_nlevels : cd.enc_nlevels) : (int)(hdr1 & 0x7FFFFFFFu);
     const uint32_t *gs = a.static_sched ? (grouped ? cd.encg_steps : cd.enc_steps) : a.sched_steps + f * cd.m;
     const uint16_t *gle = a.static_sched ? (grouped ? cd.encg_lvlend : cd.enc_lvlend) : a.sched_lvlend + f * (cd.m + 1);
     const uint8_t *gic = a.static_sched ? (grouped ? cd.encg_invc : cd.enc_invc) : a.sched_invc + f * cd.m;
@@ -761,8 +764,25 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     // The column lists of the symbols solved in phase B go to the LDS left over behind the accumulators of this
     // frame (nsteps of nslots used), so that phase B issues no global load: a load behind the phase's row stores
     // would wait for those stores (one memory counter), once per level.  Frames without room keep the global lists.
-    const bool lds_lists = !a.static_sched && (int64_t)nsteps * (B + 4 * cdw) <= (int64_t)a.nslots * B;
+    // Paired levels (a.pairs: the schedule comes from peel_relax.inc mode 2): the steps of a group's second half pull the raw accumulators
+    // of their first-half inputs; their pull entries (two words) and every step's level (u16) go behind the lists when there is room,
+    // else the frame runs its levels one by one (they are a valid levelling on their own) without pulls and exclusions.
+    const bool pairs_f = !a.static_sched && a.pairs && (hdr1 >> 31) && a.xl_setup && (int64_t)nsteps * (B + 4 * cdw + 10) + 16 <= (int64_t)a.nslots * B;
+    const bool lds_lists = !a.static_sched && (pairs_f || (int64_t)nsteps * (B + 4 * cdw) <= (int64_t)a.nslots * B);
     uint32_t *slist = reinterpret_cast<uint32_t *>(acc + (size_t)nsteps * B);   // [nsteps][cdw]
+    uint32_t *plist = slist + (size_t)nsteps * cdw;                              // [nsteps][2] pull entries (pairs_f)
+    uint16_t *slev = reinterpret_cast<uint16_t *>(plist + (size_t)nsteps * 2);   // [nsteps] level of the step (pairs_f)
+    const uint32_t *gpl = (pairs_f ? a.sched_pull : nullptr);
+    uint32_t prc[SPT][3];   // this thread's step records (level, two pulls), requested with the other set-up loads
+#pragma unroll
+    for (int u = 0; u < SPT; u++) {
+        const int s = tid + u * nthr;
+        prc[u][0] = prc[u][1] = prc[u][2] = 0xFFFFFFFFu;
+        if (pairs_f && s < nsteps) {
+            const uint32_t *r_ = gpl + ((size_t)f * cd.m + s) * 4;
+            prc[u][0] = r_[0]; prc[u][1] = r_[1]; prc[u][2] = r_[2];
+        }
+    }
     constexpr int LPT = 2;                      // list words per thread held in registers
     uint32_t lw[LPT];
     if (lds_lists) {
@@ -802,12 +822,22 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         invc[s] = (uint8_t)iv;
         rk[t] = 0;
     };
+    auto put_pull = [&](int s, uint32_t lv, uint32_t p0, uint32_t p1) {
+        // a pull entry leaves as (LDS address of the pulled accumulator slice | coef << 24), like the scatter entries
+        slev[s] = (uint16_t)lv;
+        plist[2 * s] = p0 == 0xFFFFFFFFu ? p0 : (((uint32_t)kAccOff + (p0 & 0x00FFFFFFu) * (uint32_t)B) | (p0 & 0xFF000000u));
+        plist[2 * s + 1] = p1 == 0xFFFFFFFFu ? p1 : (((uint32_t)kAccOff + (p1 & 0x00FFFFFFu) * (uint32_t)B) | (p1 & 0xFF000000u));
+    };
 #pragma unroll
     for (int u = 0; u < SPT; u++) {
         const int s = tid + u * nthr;
         if (s < nsteps) put_step(s, stp[u], siv[u]);
+        if (pairs_f && s < nsteps) put_pull(s, prc[u][0], prc[u][1], prc[u][2]);
     }
-    for (int s = tid + SPT * nthr; s < nsteps; s += nthr) put_step(s, gs[s], gic[s]);
+    for (int s = tid + SPT * nthr; s < nsteps; s += nthr) {
+        put_step(s, gs[s], gic[s]);
+        if (pairs_f) { const uint32_t *r_ = gpl + ((size_t)f * cd.m + s) * 4; put_pull(s, r_[0], r_[1], r_[2]); }
+    }
     if (lds_lists) {
         // The lists go to LDS TRANSLATED (check -> LDS address of the step's accumulator slice | coef << 24, the form the turns of
         // `scatter` consume; the list's own step left out): the two dependent look-ups of the translation then happen once, here,
@@ -816,7 +846,13 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         auto xl = [&](uint32_t w, uint32_t own) -> uint32_t {
             if (!a.xl_setup) return w;
             const uint32_t s_ = soc[w == 0xFFFFFFFFu ? 0u : (w & 0xFFFFu)];
-            return (w != 0xFFFFFFFFu && s_ != 0xFFFFu && s_ != own) ? (((uint32_t)kAccOff + s_ * (uint32_t)B) | ((w & 0x00FF0000u) << 8)) : 0xFFFFFFFFu;
+            bool keep = w != 0xFFFFFFFFu && s_ != 0xFFFFu && s_ != own;
+            if (pairs_f) {   // a first half (odd level) does not scatter into the second half of its own group: those steps pull instead
+                const uint32_t lo = slev[own];
+                const uint32_t x0 = lvlend[lo], x1 = lvlend[min((int)lo + 1, nlev)];
+                keep = keep && !((lo & 1u) && s_ >= x0 && s_ < x1);
+            }
+            return keep ? (((uint32_t)kAccOff + s_ * (uint32_t)B) | ((w & 0x00FF0000u) << 8)) : 0xFFFFFFFFu;
         };
 #pragma unroll
         for (int u = 0; u < LPT; u++) {
@@ -1192,8 +1228,17 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         };
         uint32_t ewn[KQ];
         if (!LL) load_list((nlev >= 1 ? (int)lvlend[0] : 0) + wave * RPW + g, nlev >= 1 ? (int)lvlend[1] : 0, ewn);
-        for (int L = 1; L <= nlev; L++) {
-            const int s0 = lvlend[L - 1], s1 = lvlend[L];
+        const bool paired = MODE == 1 && pairs_f;   // groups of two levels behind one barrier; the second half pulls (see pairs_f)
+#ifdef LDPC_AMD_MLDBG
+        // diagnostic (WRONG bytes, timing only; tools/bound_cfg3.py): bit 64 = every step of the frame as ONE level, bit 128 = the
+        // levels taken in pairs: what collapsing the decoder's levels the way the encoder's are collapsed could gain at most
+        const int lstep = (a.dbg & 64) ? (nlev > 0 ? nlev : 1) : (((a.dbg & 128) || paired) ? 2 : 1);
+#else
+        const int lstep = paired ? 2 : 1;
+#endif
+        for (int L = 1; L <= nlev; L += lstep) {
+            const int s0 = lvlend[L - 1], s1 = lvlend[min(L + lstep - 1, nlev)];
+            const int smid = lvlend[L];   // (paired: the group's second half starts here)
             for (int sb = s0 + wave * RPW; sb < s1; sb += nw * RPW) {
                 const int s = sb + g;
                 U4 val = {0, 0, 0, 0};
@@ -1206,8 +1251,19 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
                 }
                 if (s < s1) {
                     const int t = tgt[s];
-                    const U4 a16 = kSplit ? lds_read16_split(acc + (size_t)s * B, gl, B / 2)
-                                          : *reinterpret_cast<const U4 *>(acc + (size_t)s * B + gl * 16);
+                    U4 a16 = kSplit ? lds_read16_split(acc + (size_t)s * B, gl, B / 2)
+                                    : *reinterpret_cast<const U4 *>(acc + (size_t)s * B + gl * 16);
+                    if (paired && s >= smid) {
+#pragma unroll
+                        for (int q = 0; q < 2; q++) {
+                            const uint32_t pe = plist[2 * s + q];
+                            if (pe != 0xFFFFFFFFu) {
+                                const unsigned char *src_ = smem + (pe & 0x00FFFFFFu);
+                                const U4 sv_ = kSplit ? lds_read16_split(src_, gl, B / 2) : *reinterpret_cast<const U4 *>(src_ + gl * 16);
+                                gfmac16(a16, lds_multab_at(pe >> 19), sv_);
+                            }
+                        }
+                    }
                     val = gfmul16(lds_multab(mt, invc[s]), a16);
                     stream_store16<NT>(out_row(t), val);
                 }
@@ -2089,6 +2145,8 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     // ---- exact time-stamp relaxation instead of the serial per-solve loop (peel_relax.inc) when the keys fit 16 bits: S = 1 decode
     //      (mode 0), the pattern-only runs (mode 1), the packet path's schedules (mode 2).  The encoder's one-sweep chain and
     //      everything else keep ldpc_peel_kernel.  Returns 1: launched, 0: not applicable, < 0: error.
+    uint32_t *pa_pull = nullptr;   // packets: per-step records of the paired-level schedules (peel_relax.inc mode 2 -> packet kernel)
+    int pa_pairs = 0;
     int logM = 0;
     while ((1 << logM) < cd.mpad) logM++;
     const bool relax_ok = kn.peel_relax != 0 && d.erased != nullptr && d.in_rows == cd.n && cd.degpad <= 16 && cd.n <= 32767 &&
@@ -2103,6 +2161,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         ra.ml_list = (int32_t *)ctx->mllist.p; ra.ml_state = (uint8_t *)ctx->mlstate.p;
         ra.sched_hdr = pa.sched_hdr; ra.sched_steps = pa.sched_steps; ra.sched_lvlend = pa.sched_lvlend; ra.sched_invc = pa.sched_invc;
         ra.big_list = pa.big_list; ra.tcap = pa.tcap;
+        ra.sched_pull = pa_pull; ra.pairs = (mode == 2 && pa_pull) ? 1 : 0;
         // LDS plan: per frame its keys / values, solver and order lists (packets: + the level histogram); the code tables once per
         // workgroup (or from global memory).  Frames per CU = workgroups per CU x wavefronts per workgroup; the tables in LDS for short
         // batches (a single round is latency bound), in global memory when the batch is deep and that puts >= 1.3x more frames on a CU
@@ -2118,8 +2177,12 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             Lr.key = w; w += align_up(2 * (cd.n + 1), 16);
             Lr.fire = w; w += align_up(2 * cd.mpad, 16);
             Lr.order = w; w += align_up(2 * cd.mpad, 16);
-            Lr.cnt = w; w += 256;
-            Lr.hist = w; if (mode == 2) w += align_up(4 * (cd.m + 2), 16);
+            // (mode 2: the per-sweep counts of the time sort live at the start of the level histogram, which is not in use yet then --
+            // with them apart the (2040,1530) frame state is 9472 bytes and only 15 frames fit a CU: a 4096-frame batch needs 16)
+            Lr.cnt = w; if (mode != 2) w += 256;
+            Lr.hist = w; if (mode == 2) w += align_up(std::max(4 * (cd.m + 2), 256), 16);
+            Lr.dep = w; if (mode == 2) w += align_up(cd.mpad, 16);
+            Lr.sinv = w; if (mode == 2) w += align_up(cd.mpad, 16);
             Lr.wave_stride = w;
             Lr.total = off + w_ * w;
         };
@@ -2207,8 +2270,13 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             pa.big_list = plan.two_tier ? (int32_t *)ctx->biglist.p : nullptr;
         }
         hipEvent_t ev = nullptr;
+        if (use_scatter && relax_ok && kn.scatter_pairs != 0) {   // paired levels: 16 bytes per step for the records the packet kernel reads at set-up
+            if ((rc = scratch_reserve(ctx, ctx->schedpull, (size_t)nf * cd.m * 16))) return rc;
+            pa_pull = (uint32_t *)ctx->schedpull.p;
+        }
         const int rl = relax_launch(2);   // the schedules by relaxation when its keys fit (else, and with PEEL_RELAX=0: the serial loop)
         if (rl < 0) return rl;
+        pa_pairs = (rl > 0 && pa_pull) ? 1 : 0;
         if (rl == 0) {
             ev = prof_begin(ctx);
             LDPC_HIP_TRY(ctx, launch_peel_t<false>(pa, wpb, ctx->stream));
@@ -2228,6 +2296,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             sa.code = cd; sa.S = d.S; sa.nslices = plan.nslices; sa.nframes = nf; sa.sym = d.sym; sa.erased = d.erased; sa.out = d.out;
             sa.in_rows = cd.n; sa.static_sched = 0; sa.inplace = d.inplace;
             sa.dbg = kn.ml_dbg; sa.err = ctx->dev_err_host; sa.xl_setup = kn.scatter_xl;
+            sa.sched_pull = pa_pull; sa.pairs = pa_pairs;
             sa.sched_hdr = pa.sched_hdr; sa.sched_steps = pa.sched_steps; sa.sched_lvlend = pa.sched_lvlend;
             sa.sched_invc = pa.sched_invc;
             ev = prof_begin(ctx);

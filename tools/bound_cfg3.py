@@ -7,6 +7,8 @@
       streamed and written once, <= tcap accumulators); the second pass (re-stream the rows the later steps consume) comes on top.
   (c) (round 4) chain composition in the solve schedules: bits 4096 / 8192 leave out the barrier behind all but every second / fourth level of
       the solve kernel -- what a schedule with half / a quarter of the levels could gain at most (the ops stay).
+  (e) (round 4) the DECODER's dependency levels collapsed the way the encoder's static schedule is (groups of levels, steps pulling in-group
+      accumulators): bit 128 takes the levels of the packet kernels in pairs, bit 64 all steps of a frame as one level -- the most it could gain.
   (b) right-hand sides of the ML systems built inside the packet stream: bit 16384 skips level 0 of the solve kernel (the known-row
       re-read and its multiply-accumulates) -- the most (b) could remove, before the cost of doing the same products in the packet
       kernel and of moving the finished right-hand sides through HBM.
@@ -46,12 +48,13 @@ def main():
     res = {}
     for rnd in range(5):
         for name, dbg in (("product path", 0), ("(a) tier 1 takes every frame, cut off at tcap steps; no tier 2", 32768), ("(b) solve kernel without level 0", 16384),
+                          ("(e) ML_PI=2, packet kernels: the levels of a frame taken in pairs", 128), ("(e) ML_PI=2, packet kernels: every step of a frame as ONE level", 64),
                           ("fast path without its consistency test (ML_PI=2)", -2),
                           ("(c) ML_PI=2, solve kernel: barrier behind every second level only", 4096), ("(c) ML_PI=2, ... behind every fourth level only", 8192),
                           ("(c) ML_PI=2, every forward / backward op as ONE level", 256)):
             # (the (c) runs produce wrong bytes, which the consistency test of the default mode would flag and redo: they run without it,
             # next to a baseline without it)
-            ctx.configure("ML_PI", "2" if dbg in (-2, 4096, 8192, 256) else None)
+            ctx.configure("ML_PI", "2" if dbg in (-2, 4096, 8192, 256, 64, 128) else None)
             ctx.configure("ML_DBG", max(dbg, 0))
             ctx.get_profile(); ctx.set_profiling(True)
             ctx.decode(h, sym, era, out=out, status=st)
