@@ -85,3 +85,77 @@ def test_every_cap_and_random_triangle_codes(oracle, cap):
             src1 = synth.source(5, 0, 4, code.k, 1)[:, :, 0]          # the S = 1 encoder is the peel kernel: unaffected
             cw1 = ctx.encode(h, src1)
             assert np.array_equal(cw1[2], oc.encode(src1[2]))
+
+
+# ---- the time-stamp relaxation (csrc/peel_relax.inc) against the serial per-solve loop and the oracle -------------------------------
+def _wide_row_code(rng, n, k, deg):
+    """Random code whose checks have up to `deg` neighbours (not triangular: decode only)."""
+    m = n - k
+    row_ptr, cols, coefs = [0], [], []
+    for r in range(m):
+        c = sorted(rng.choice(n, size=int(rng.integers(2, deg + 1)), replace=False).tolist())
+        cols += c
+        coefs += rng.integers(1, 256, size=len(c)).tolist()
+        row_ptr.append(len(cols))
+    return codes.Code(n, k, np.array(row_ptr, dtype=np.uint32), np.array(cols, dtype=np.uint16), np.array(coefs, dtype=np.uint8))
+
+
+@pytest.mark.parametrize("S", [1, 64])
+def test_relaxation_equals_the_serial_loop_and_the_oracle(oracle, S):
+    """PEEL_RELAX = 1 (the default) and 0 must agree on every byte and every status word -- iterations, residual counts, status --
+    for sweep caps on both sides of the relaxation's limits (62 sweeps, 16-bit keys), on codewords and on symbols that are not
+    codewords, with the ML stage on and off; a sample of frames is compared with the oracle (...Decoder.m:21-59)."""
+    rng = np.random.default_rng(40 + S)
+    cases = [(1, 0.10), (1, 0.19), (1, 0.26), (2, 0.40), (2, 0.47), (0, 0.38), (0, 0.45)]
+    with api.Context(0) as ctx:
+        for code_ind, per in cases:
+            code = codes.load_builtin(code_ind)
+            oc = oracle.OracleCode(code)
+            h = ctx.load_builtin_code(code_ind, codes.DEFAULT_COEF_SEED[code_ind])
+            F = 24
+            src = synth.source(7 * code_ind + 1, 0, F, code.k, S)
+            cw = ctx.encode(h, src if S > 1 else src[:, :, 0])
+            era = synth.erasures_uniform(50 + code_ind, int(per * 100), F, code.n, per)
+            sym = cw.copy()
+            sym[era.astype(bool)] = 0x77
+            for f in range(0, F, 5):                       # every fifth frame: two received symbols corrupted (not a codeword)
+                known = np.flatnonzero(era[f] == 0)
+                for j in rng.choice(known, size=2, replace=False):
+                    sym[f, j] ^= 0x21
+            for sweeps, do_ml in ((1, 1), (3, 0), (10, 1), (50, 1), (62, 0), (63, 1), (200, 0)):
+                ctx.configure("PEEL_RELAX", "1")
+                a = ctx.decode(h, sym, era, max_sweeps=sweeps, do_ml=do_ml)
+                used = ctx.profile_kernel_names()["peel"]
+                ctx.configure("PEEL_RELAX", "0")
+                b = ctx.decode(h, sym, era, max_sweeps=sweeps, do_ml=do_ml)
+                ctx.configure("PEEL_RELAX", None)
+                for x, y, what in zip(a, b, ("out", "sweeps", "residual", "status")):
+                    assert np.array_equal(x, y), (code_ind, per, sweeps, do_ml, what)
+                logm = int(np.ceil(np.log2(max(64, -(-code.m // 64) * 64))))
+                fits = sweeps <= 62 and ((sweeps + 1) << logm) <= 65535
+                assert ("relax" in used) == fits, (code_ind, sweeps, used)      # the fall-back is taken exactly when the keys do not fit
+                if sweeps == 10 and do_ml == 1:
+                    for f in (0, 5, F - 1):
+                        if S == 1:
+                            o = oc.decode_batch_s1(sym[f:f + 1], era[f:f + 1])
+                            assert np.array_equal(a[0][f], o[0][0]) and a[1][f] == o[1][0] and a[2][f] == o[2][0] and a[3][f] == o[3][0], (code_ind, per, f)
+                        else:
+                            o, _, it, info, rc = oc.decode_packets(sym[f], era[f])
+                            assert a[1][f] == it and a[2][f] == info[0], (code_ind, per, f)
+                            if not (rc == -2 or not info[1]):
+                                assert np.array_equal(a[0][f], o), (code_ind, per, f)
+        # a code whose checks are wider than the relaxation's 16 neighbours: the serial kernel takes it, same results as the oracle
+        code = _wide_row_code(rng, 600, 300, 22)
+        oc = oracle.OracleCode(code)
+        h = ctx.register_code(code)
+        symw = rng.integers(0, 256, size=(6, code.n) if S == 1 else (6, code.n, S), dtype=np.uint8)
+        eraw = synth.erasures_uniform(3, 0, 6, code.n, 0.08)
+        out = ctx.decode(h, symw, eraw, max_sweeps=10, do_ml=0)
+        assert "relax" not in ctx.profile_kernel_names()["peel"]
+        for f in range(6):
+            if S == 1:
+                o = oc.decode_batch_s1(symw[f:f + 1], eraw[f:f + 1], do_ml=0)
+                assert np.array_equal(out[0][f], o[0][0]) and out[1][f] == o[1][0] and out[2][f] == o[2][0]
+            else:
+                o, _, it, info, rc = oc.decode_packets(symw[f], eraw[f], do_ml=0)
+                assert np.array_equal(out[0][f], o) and out[1][f] == it and out[2][f] == info[0]
