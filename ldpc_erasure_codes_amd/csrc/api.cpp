@@ -170,7 +170,7 @@ int check_device_error(ldpc_amd_ctx *ctx)
     if (!ctx->dev_err_host) return LDPC_AMD_OK;
     const int bits = __atomic_exchange_n(ctx->dev_err_host, 0, __ATOMIC_ACQ_REL);
     if (!bits) return LDPC_AMD_OK;
-    return set_error(ctx, LDPC_AMD_EHIP, "a kernel reported a violated internal assumption (bits 0x%x: 1 = dynamic LDS not at LDS address 0); "
+    return set_error(ctx, LDPC_AMD_EHIP, "a kernel reported a violated internal assumption (bits 0x%x: 1 = dynamic LDS not at LDS address 0, 2 = a loop of the relaxation kernel hit its safety cap); "
                      "the frames it handled were left undecoded", bits);
 }
 

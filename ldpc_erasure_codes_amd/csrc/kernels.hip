@@ -62,6 +62,7 @@ __device__ __forceinline__ uint32_t uniform(uint32_t v) { return __builtin_amdgc
 constexpr int kMlClasses = 16, kMlHdr = 32;
 // bits of the context's device-error word (pinned host memory the kernels write to directly; read by check_device_error)
 constexpr int kDevErrLdsBase = 1;   // a kernel that encodes absolute LDS addresses found its dynamic LDS not at address 0
+constexpr int kDevErrRelaxCap = 2;  // a loop of ldpc_peel_relax_kernel ran into its safety cap (never in a correct run)
 
 // Diagnostic build only (-DLDPC_AMD_STAMPS, tools/stamp_peel.py): per-phase cycle sums of the peel kernel go to a
 // buffer nothing else reads.  The product build contains no stamp.
@@ -2158,7 +2159,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         ra.rx_off = cd.rx_off; ra.ell_logc = cd.ell_logc; ra.ell_coef = cd.ell_coef;
         ra.nframes = nf; ra.sym = d.sym; ra.erased = d.erased; ra.max_sweeps = d.max_sweeps; ra.do_ml = mode == 1 ? 0 : d.do_ml;
         ra.out = d.out; ra.sweeps = d.sweeps; ra.residual = d.residual; ra.status = d.status; ra.residual_sys = d.residual_sys;
-        ra.ml_list = (int32_t *)ctx->mllist.p; ra.ml_state = (uint8_t *)ctx->mlstate.p;
+        ra.ml_list = (int32_t *)ctx->mllist.p; ra.ml_state = (uint8_t *)ctx->mlstate.p; ra.err = ctx->dev_err_host;
         ra.sched_hdr = pa.sched_hdr; ra.sched_steps = pa.sched_steps; ra.sched_lvlend = pa.sched_lvlend; ra.sched_invc = pa.sched_invc;
         ra.big_list = pa.big_list; ra.tcap = pa.tcap;
         ra.sched_pull = pa_pull; ra.pairs = (mode == 2 && pa_pull) ? 1 : 0;

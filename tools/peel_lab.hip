@@ -25,6 +25,7 @@ namespace {
 struct alignas(16) U4 { uint32_t x, y, z, w; };
 constexpr int kWave = 64;
 constexpr int kMlClasses = 16, kMlHdr = 32;
+constexpr int kDevErrRelaxCap = 2;
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ int wave_id() { return (int)(threadIdx.x >> 6); }
 __device__ __forceinline__ void wave_sync()
