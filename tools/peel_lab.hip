@@ -65,8 +65,8 @@ int main(int argc, char **argv)
     fclose(fp);
     rng_state = strtoull(argv[2], nullptr, 10);
     const int F = atoi(argv[3]);
-    const bool bursty = !strcmp(argv[4], "bursty");
-    const double per = bursty ? 0.0 : atof(argv[4]);
+    const bool bursty = !strcmp(argv[4], "bursty"), parity = !strcmp(argv[4], "parity");   // parity: every parity symbol erased (one long chain)
+    const double per = (bursty || parity) ? 0.0 : atof(argv[4]);
     const int max_sweeps = atoi(argv[5]);
     int wpb_arg = argc > 6 ? atoi(argv[6]) : 0;
     const int gt = argc > 7 ? atoi(argv[7]) : 0, U = argc > 8 ? atoi(argv[8]) : 1, inner_max = argc > 9 ? atoi(argv[9]) : 0;
@@ -115,6 +115,8 @@ int main(int argc, char **argv)
             if (bursty) {   // Gilbert-Elliott like bench.py's cfg 3 (alpha 0.13, beta 0.8, bias 10)
                 e = uni() < (state ? 0.8 : 0.13);
                 state = state ? (uni() < 0.1 ? 0 : 1) : (uni() < 0.01 ? 1 : 0);
+            } else if (parity) {
+                e = j >= k || uni() < 0.01;
             } else {
                 e = uni() < per;
             }
