@@ -89,6 +89,7 @@ static const KnobDesc kKnobs[] = {
     LDPC_KNOB_INT("SCATTER_T2B", scatter_t2b, x == 256 || x == 128),
     LDPC_KNOB_INT("SCATTER_XL", scatter_xl, x == 0 || x == 1),
     LDPC_KNOB_INT("SCATTER_PAIRS", scatter_pairs, x == 0 || x == 1),
+    LDPC_KNOB_INT("SCATTER_LISTS", scatter_lists, x == 0 || x == 1),
     LDPC_KNOB_INT("PEEL_WPB", peel_wpb, x >= 0 && x <= 16),
     LDPC_KNOB_INT("PEEL_GT", peel_gt, x >= -1 && x <= 1),
     LDPC_KNOB_INT("PEEL_RELAX", peel_relax, x == 0 || x == 1),
@@ -812,7 +813,7 @@ void ldpc_amd_cleanup(ldpc_amd_ctx *ctx)
         delete r;
     }
     Scratch *all[] = {&ctx->sched, &ctx->mlws, &ctx->mlstate, &ctx->mlops, &ctx->mlrec, &ctx->mllist, &ctx->biglist, &ctx->stage_in, &ctx->stage_er,
-                      &ctx->stage_out, &ctx->stage_i32, &ctx->schedpull, &ctx->rsws, &ctx->rsbad, &ctx->fpga_erased, &ctx->fpga_stats};
+                      &ctx->stage_out, &ctx->stage_i32, &ctx->schedpull, &ctx->schedlists, &ctx->rsws, &ctx->rsbad, &ctx->fpga_erased, &ctx->fpga_stats};
     for (Scratch *s : all) scratch_free(*s);
     for (auto &v : ctx->prof_events)
         for (auto &pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }

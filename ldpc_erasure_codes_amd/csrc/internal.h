@@ -106,6 +106,8 @@ struct Knobs {
     int scatter_dyn = 1;         // SCATTER_DYN: 1 LDS counter, 0 fixed stride, 2 compacted list, 3 sorted list, 4 list sorted inside 64-row windows
     int scatter_r = 2;           // SCATTER_R: row pieces in flight per lane group, tier 1 (1, 2, 4)
     int scatter_r2 = 3;          // SCATTER_R2: ... tier 2 (2, 3, 4)
+    int scatter_lists = 0;       // SCATTER_LISTS: the relaxation's schedules carry the steps' column lists (set-up of the packet kernel: one global round trip
+                                 // instead of two).  Measured: packet kernels unchanged (3.143 / 4.327 / 6.439 against 3.138 / 4.334 / 6.442 ms), peel +0.005...0.06: off
     int scatter_pairs = 1;       // SCATTER_PAIRS: the relaxation's schedules group the levels in pairs (one barrier per pair, second halves pull); 0: plain levels
     int scatter_xl = 1;          // SCATTER_XL: the level phase's lists are translated to accumulator addresses at set-up (0: inside every level)
     int scatter_t2b = 256;       // SCATTER_T2B: bytes of every row per TIER-2 workgroup (256: one workgroup per CU; 128: two)
@@ -163,6 +165,7 @@ struct ldpc_amd_ctx {
     std::vector<ldpc_amd::HostRs *> rs;
     // workspaces
     ldpc_amd::Scratch sched;    // per-frame schedules (packet path)
+    ldpc_amd::Scratch schedlists;  // ... the steps' column lists in schedule order (relaxation schedules)
     ldpc_amd::Scratch schedpull;   // ... their per-step records when the levels come in pairs (16 bytes per step)
     ldpc_amd::Scratch mlws;     // ML stage matrices
     ldpc_amd::Scratch mlstate;  // residual erasure masks of the frames handed to the ML stage

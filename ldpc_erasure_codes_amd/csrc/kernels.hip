@@ -610,6 +610,7 @@ struct ScatterArgs {
     int lds_soc_bytes;        // size of the row-kind / row-list region
     int enc_list;             // encode: stream the source rows in DevCode::enc_order
     int enc_clist;            // encode: the level phase reads DevCode::enc_lst from LDS (copied over the dead row tables at lds_soc)
+    const uint32_t *sched_lists;  // [nframes][m][cdw] the steps' column lists in schedule order (peel_relax.inc mode 2), or nullptr
     const uint32_t *sched_pull;   // [nframes][m][4] pairs: level of the step, two pulled accumulators (slot | coef << 24), spare (peel_relax.inc mode 2)
     int pairs;                // the schedules' levels come in groups of two (first / second half): one barrier per group, second halves pull
     int xl_setup;             // level-phase lists translated (check -> accumulator address) at set-up instead of inside every level
@@ -792,8 +793,12 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
             const int e = tid + u * nthr;
             lw[u] = 0xFFFFFFFFu;
             if (e < nsteps * cdw) {
-                const int s = e / cdw, idx = e - s * cdw;
-                lw[u] = cd.cell[((int64_t)(gs[s] >> 16) << cd.cdw_shift) + idx];
+                if (a.sched_lists) {   // (the peel kernel laid the lists out in schedule order: no dependent step -> symbol -> list load)
+                    lw[u] = a.sched_lists[(size_t)f * cd.m * cdw + e];
+                } else {
+                    const int s = e / cdw, idx = e - s * cdw;
+                    lw[u] = cd.cell[((int64_t)(gs[s] >> 16) << cd.cdw_shift) + idx];
+                }
             }
         }
     }
@@ -862,7 +867,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         }
         for (int e = tid + LPT * nthr; e < nsteps * cdw; e += nthr) {
             const int s = e / cdw, idx = e - s * cdw;
-            slist[e] = xl(cd.cell[((int64_t)(gs[s] >> 16) << cd.cdw_shift) + idx], (uint32_t)s);
+            slist[e] = xl(a.sched_lists ? a.sched_lists[(size_t)f * cd.m * cdw + e] : cd.cell[((int64_t)(gs[s] >> 16) << cd.cdw_shift) + idx], (uint32_t)s);
         }
     }
     __syncthreads();
@@ -2146,6 +2151,8 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     // ---- exact time-stamp relaxation instead of the serial per-solve loop (peel_relax.inc) when the keys fit 16 bits: S = 1 decode
     //      (mode 0), the pattern-only runs (mode 1), the packet path's schedules (mode 2).  The encoder's one-sweep chain and
     //      everything else keep ldpc_peel_kernel.  Returns 1: launched, 0: not applicable, < 0: error.
+    uint32_t *pa_lists = nullptr;  // packets: the steps' column lists in schedule order (peel_relax.inc mode 2 -> packet kernel set-up)
+    bool pa_lists_on = false;
     uint32_t *pa_pull = nullptr;   // packets: per-step records of the paired-level schedules (peel_relax.inc mode 2 -> packet kernel)
     int pa_pairs = 0;
     int logM = 0;
@@ -2163,6 +2170,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         ra.sched_hdr = pa.sched_hdr; ra.sched_steps = pa.sched_steps; ra.sched_lvlend = pa.sched_lvlend; ra.sched_invc = pa.sched_invc;
         ra.big_list = pa.big_list; ra.tcap = pa.tcap;
         ra.sched_pull = pa_pull; ra.pairs = (mode == 2 && pa_pull) ? 1 : 0;
+        ra.sched_lists = mode == 2 ? pa_lists : nullptr; ra.cell = cd.cell; ra.cdw = cd.maxcoldeg; ra.cdw_shift = cd.cdw_shift;
         // LDS plan: per frame its keys / values, solver and order lists (packets: + the level histogram); the code tables once per
         // workgroup (or from global memory).  Frames per CU = workgroups per CU x wavefronts per workgroup; the tables in LDS for short
         // batches (a single round is latency bound), in global memory when the batch is deep and that puts >= 1.3x more frames on a CU
@@ -2275,9 +2283,14 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             if ((rc = scratch_reserve(ctx, ctx->schedpull, (size_t)nf * cd.m * 16))) return rc;
             pa_pull = (uint32_t *)ctx->schedpull.p;
         }
+        if (use_scatter && relax_ok && kn.scatter_lists != 0) {
+            if ((rc = scratch_reserve(ctx, ctx->schedlists, (size_t)nf * cd.m * cd.maxcoldeg * 4))) return rc;
+            pa_lists = (uint32_t *)ctx->schedlists.p;
+        }
         const int rl = relax_launch(2);   // the schedules by relaxation when its keys fit (else, and with PEEL_RELAX=0: the serial loop)
         if (rl < 0) return rl;
         pa_pairs = (rl > 0 && pa_pull) ? 1 : 0;
+        pa_lists_on = rl > 0 && pa_lists;
         if (rl == 0) {
             ev = prof_begin(ctx);
             LDPC_HIP_TRY(ctx, launch_peel_t<false>(pa, wpb, ctx->stream));
@@ -2297,7 +2310,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             sa.code = cd; sa.S = d.S; sa.nslices = plan.nslices; sa.nframes = nf; sa.sym = d.sym; sa.erased = d.erased; sa.out = d.out;
             sa.in_rows = cd.n; sa.static_sched = 0; sa.inplace = d.inplace;
             sa.dbg = kn.ml_dbg; sa.err = ctx->dev_err_host; sa.xl_setup = kn.scatter_xl;
-            sa.sched_pull = pa_pull; sa.pairs = pa_pairs;
+            sa.sched_pull = pa_pull; sa.pairs = pa_pairs; sa.sched_lists = pa_lists_on ? pa_lists : nullptr;
             sa.sched_hdr = pa.sched_hdr; sa.sched_steps = pa.sched_steps; sa.sched_lvlend = pa.sched_lvlend;
             sa.sched_invc = pa.sched_invc;
             ev = prof_begin(ctx);

@@ -1,9 +1,10 @@
 #!/bin/bash
-# Diagnostic build of the library with -DLDPC_AMD_STAMPS (per-phase cycle counters) -> tools/bin/ (git-ignored; travels with gpurun).
+# Diagnostic builds of the library -> tools/bin/ (git-ignored; travels with gpurun):
+#   libldpc_erasure_amd_stamps.so   -DLDPC_AMD_STAMPS  per-phase cycle counters (tools/stamp_*.py)
+#   libldpc_erasure_amd_mldbg.so    -DLDPC_AMD_MLDBG   timing-only variants with WRONG bytes (tools/bound_cfg3.py, tools/sens_ml.py)
 set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
-SRC="$ROOT/ldpc_erasure_codes_amd/csrc"
 mkdir -p "$ROOT/tools/bin"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-strict-aliasing -DLDPC_AMD_STAMPS ${EXTRA_HIPCC_FLAGS:-} -shared \
-    -o "$ROOT/tools/bin/libldpc_erasure_amd_stamps.so" "$SRC/kernels.hip" "$SRC/api.cpp" "$SRC/wire.cpp"
-echo "$ROOT/tools/bin/libldpc_erasure_amd_stamps.so"
+which="${1:-stamps}"
+if [ "$which" = "stamps" ]; then FLAG=-DLDPC_AMD_STAMPS; else FLAG=-DLDPC_AMD_MLDBG; fi
+EXTRA_HIPCC_FLAGS=$FLAG LDPC_AMD_OUT="$ROOT/tools/bin/libldpc_erasure_amd_$which.so" LDPC_AMD_OBJDIR="/tmp/obj_$which" bash "$ROOT/ldpc_erasure_codes_amd/csrc/build.sh"

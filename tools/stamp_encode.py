@@ -68,7 +68,16 @@ def main():
             tot = sum(buf[i] for i in PHASES)
             print(f"decoder, bursty channel of cfg 3 (both tiers): {tot / F:.0f} cycles per frame")
             for i, name in PHASES.items():
-                print(f"   {name:48s} {100.0 * buf[i] / max(tot, 1):5.1f} %")
+                print(f"   {name:48s} {100.0 * buf[i] / max(tot, 1):5.1f} %   ({buf[i] / F:.0f})")
+            for knob, val in (("SCATTER_PAIRS", "0"), ("SCATTER_XL", "0"), ("PEEL_RELAX", "0")):   # round 4: what each of the three changes does to the phases
+                ctx.configure("LDPC_AMD_ML_PI", "0"); ctx.configure("LDPC_AMD_ML_OVERLAP", "0"); ctx.configure(knob, val)
+                ctx.decode(h, cw, era, out=out)
+                L.ldpc_amd_debug_peel_stamps(ctx._h, buf, 1)
+                ctx.decode(h, cw, era, out=out)
+                L.ldpc_amd_debug_peel_stamps(ctx._h, buf, 1)
+                ctx.configure(knob, None); ctx.configure("LDPC_AMD_ML_PI", None); ctx.configure("LDPC_AMD_ML_OVERLAP", None)
+                tot2 = sum(buf[i] for i in PHASES)
+                print(f"   ... with {knob}={val}: {tot2 / F:.0f} cycles per frame: " + ", ".join(f"{buf[i] / F:.0f}" for i in PHASES))
         del src_t, cw, era, out
         torch.cuda.empty_cache()
     ctx.close()
