@@ -882,6 +882,7 @@ def main():
         block = {"cfg4": run_cfg4(g, args)} if args.S == 1 else {"cfg4_S1024": run_cfg4_packets(g, args, args.S)}
     else:
         block = {"cfg5": run_cfg5(g, args, args.total_frames or WORKLOADS["cfg5"]["frames"], args.gather, S=args.cfg5_S)}
+    non_default_knobs = g.ctx.knobs()   # (LDPC_AMD_* variables of the environment this process started under; '' = the shipped defaults)
     g.close()
     if rank != 0:
         return
@@ -999,6 +1000,7 @@ def main():
     # ---- ONE line on stdout, short enough for the driver's tail: the required keys, `roofline`, `cpu_baseline`
     # and a flat per-config `summary` LAST; everything else (per-kernel name maps, workload prose, histograms, the ML stage's other
     # modes, the CPU legs' sample texts) goes to the detail file written by this same run.
+    line["non_default_knobs"] = non_default_knobs
     detail_rel = os.path.join("profiles", "round4_bench_detail.json")
     written = []
     for dpath in (os.path.join(ROOT, detail_rel), os.path.join(ROOT, "gpurun_out", "round4_bench_detail.json")):
@@ -1089,6 +1091,8 @@ def compact_line(line, detail_file):
                                "cpu_model": cb.get("cpu_model")}
         out["gpu_over_cpu"] = _r(line.get("gpu_over_cpu"), 4)
     out["detail_file"] = detail_file
+    if line.get("non_default_knobs"):
+        out["non_default_knobs"] = line["non_default_knobs"]   # a measurement under LDPC_AMD_* variables says so in the line
     sm = {}
     cfgs = line.get("configs") or {}
     for name in ("sustained", "pipelined_two_contexts"):

@@ -75,6 +75,10 @@ int ldpc_amd_synchronize(ldpc_amd_ctx *ctx);
  * reference's command-line options, OpenCL/host/src/main.cpp:157-170,217-246).  A knob changes how a batch is decoded, never a
  * byte of the result.  LDPC_AMD_EINVAL for an unknown key or a value outside the knob's range. */
 int ldpc_amd_configure(ldpc_amd_ctx *ctx, const char *key, const char *value);
+/* The knobs of this context that differ from the shipped defaults, as "NAME=value NAME=value" (word-valued knobs as 0 / 1) into
+ * buf (at most cap - 1 characters + NUL; buf may be NULL); returns the length of the full text: 0 = everything at its default.  For
+ * measurement scripts that want to print what they actually measured (bench.py writes it into its detail file). */
+int ldpc_amd_knobs(ldpc_amd_ctx *ctx, char *buf, int cap);
 
 /* ---- code ROM ----------------------------------------------------------------------------------
  * ldpc_amd_code_params: the row ldpc_params[code_ind][0..5] = {n, k, firstRow, lastRow, RS_n, RS_k}

@@ -33,7 +33,7 @@ PROF_KINDS = ("peel", "apply", "ml", "apply_tier2", "ml_solve")
 # every symbol include/ldpc_erasure_amd.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "ldpc_amd_init", "ldpc_amd_cleanup", "ldpc_amd_last_error", "ldpc_amd_set_stream", "ldpc_amd_synchronize", "ldpc_amd_configure",
-    "ldpc_amd_code_params", "ldpc_amd_load_builtin_code", "ldpc_amd_register_code", "ldpc_amd_code_info", "ldpc_amd_encode_info",
+    "ldpc_amd_code_params", "ldpc_amd_load_builtin_code", "ldpc_amd_register_code", "ldpc_amd_code_info", "ldpc_amd_encode_info", "ldpc_amd_knobs",
     "ldpc_amd_code_csr", "ldpc_amd_decode_batch", "ldpc_amd_encode_batch", "ldpc_amd_rs_create",
     "ldpc_amd_rs_generator", "ldpc_amd_rs_encode_batch", "ldpc_amd_rs_decode_batch", "ldpc_amd_rs_bad_blocks", "ldpc_amd_synth_source",
     "ldpc_amd_synth_erasures_uniform", "ldpc_amd_synth_erasures_bursty", "ldpc_amd_data_in", "ldpc_amd_data_in_at",
@@ -89,6 +89,8 @@ def load_library():
     L.ldpc_amd_register_code.argtypes = [vp, i32, i32, vp, vp, vp]
     L.ldpc_amd_code_info.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.ldpc_amd_encode_info.argtypes = [vp, i32, C.POINTER(i32)]
+    if hasattr(L, "ldpc_amd_knobs"):
+        L.ldpc_amd_knobs.argtypes = [vp, C.c_char_p, i32]
     # multi-device layer (include/ldpc_erasure_amd_multi.h)
     L.ldpc_amd_shard_frames.argtypes = [i64, i32, i32, C.POINTER(i64), C.POINTER(i64)]
     L.ldpc_amd_shard_frames.restype = None
@@ -230,6 +232,12 @@ class Context:
         default.  The LDPC_AMD_* environment variables are only the initial values, read once when the context is created."""
         v = None if value is None else str(value).encode()
         self._check(self._L.ldpc_amd_configure(self._h, key.encode(), v), "configure")
+
+    def knobs(self):
+        """The knobs of this context that are NOT at their shipped default, "NAME=value NAME=value" ('' = all defaults)."""
+        buf = C.create_string_buffer(1024)
+        self._check(self._L.ldpc_amd_knobs(self._h, buf, 1024), "knobs")
+        return buf.value.decode()
 
     def configure_many(self, knobs):
         """{key: value or None} -> configure() for each."""

@@ -64,6 +64,7 @@ struct KnobDesc {
     const char *name;                                    // without the LDPC_AMD_ prefix
     bool (*set)(Knobs &, const char *value);             // value != nullptr
     void (*reset)(Knobs &);                              // back to the shipped default
+    long long (*get)(const Knobs &);                     // current value (the two word-valued knobs: 0 / 1)
 };
 static bool parse_ll(const char *v, long long *out)
 {
@@ -75,10 +76,10 @@ static bool parse_ll(const char *v, long long *out)
 }
 #define LDPC_KNOB_INT(NAME, FIELD, COND)                                                                                          \
     {NAME, [](Knobs &k, const char *v) { long long x; if (!parse_ll(v, &x) || !(COND)) return false; k.FIELD = (decltype(k.FIELD))x; return true; }, \
-     [](Knobs &k) { k.FIELD = Knobs{}.FIELD; }}
+     [](Knobs &k) { k.FIELD = Knobs{}.FIELD; }, [](const Knobs &k) { return (long long)k.FIELD; }}
 static const KnobDesc kKnobs[] = {
     {"APPLY", [](Knobs &k, const char *v) { if (!strcmp(v, "gather")) k.apply_gather = 1; else if (!strcmp(v, "scatter")) k.apply_gather = 0; else return false; return true; },
-     [](Knobs &k) { k.apply_gather = 0; }},
+     [](Knobs &k) { k.apply_gather = 0; }, [](const Knobs &k) { return (long long)k.apply_gather; }},
     LDPC_KNOB_INT("SCATTER_B", scatter_b, x == 256 || x == 128 || x == 64),
     LDPC_KNOB_INT("SCATTER_TIERS", scatter_tiers, x == 1 || x == 2),
     LDPC_KNOB_INT("SCATTER_NT", scatter_nt, x == 0 || x == 1),
@@ -113,7 +114,7 @@ static const KnobDesc kKnobs[] = {
     LDPC_KNOB_INT("ENC_GROUP", enc_group, x == 0 || x == 1),
     LDPC_KNOB_INT("ENC_CAP", enc_cap, x >= 0 && x <= 64),
     {"RS", [](Knobs &k, const char *v) { if (!strcmp(v, "generic")) k.rs_generic = 1; else if (!strcmp(v, "fast")) k.rs_generic = 0; else return false; return true; },
-     [](Knobs &k) { k.rs_generic = 0; }},
+     [](Knobs &k) { k.rs_generic = 0; }, [](const Knobs &k) { return (long long)k.rs_generic; }},
     LDPC_KNOB_INT("RS_VW", rs_vw, x == 0 || x == 1 || x == 2 || x == 4),
     LDPC_KNOB_INT("HOST_PIPELINE", host_pipeline, x == 0 || x == 1),
     LDPC_KNOB_INT("FPGA_CHUNK", fpga_chunk, x >= 1),
@@ -854,6 +855,27 @@ int ldpc_amd_configure(ldpc_amd_ctx *ctx, const char *key, const char *value)
     if (knob_set(ctx->knobs, key, value))
         return set_error(ctx, LDPC_AMD_EINVAL, "ldpc_amd_configure: unknown key or bad value: %s = %s", key ? key : "(null)", value ? value : "(default)");
     return LDPC_AMD_OK;
+}
+
+int ldpc_amd_knobs(ldpc_amd_ctx *ctx, char *buf, int cap)
+{
+    if (!ctx) return LDPC_AMD_EINVAL;
+    const Knobs def{};
+    std::string out;
+    for (const KnobDesc &d : kKnobs) {
+        const long long v = d.get(ctx->knobs);
+        if (v == d.get(def)) continue;
+        if (!out.empty()) out += ' ';
+        out += d.name;
+        out += '=';
+        out += std::to_string(v);
+    }
+    if (buf && cap > 0) {
+        const size_t nb = std::min(out.size(), (size_t)cap - 1);
+        memcpy(buf, out.data(), nb);
+        buf[nb] = '\0';
+    }
+    return (int)out.size();
 }
 
 int ldpc_amd_synchronize(ldpc_amd_ctx *ctx)

@@ -122,6 +122,10 @@ def test_environment_is_read_once_at_init_and_configure_rejects_nonsense(oracle,
             c2.configure("APPLY", "scatter")                                   # ... the configure call is how it changes
             assert np.array_equal(c2.decode(h, sym, era)[0], cw)
             assert c2.last_plan()["packet_bytes_per_workgroup"] == 64
+            assert c2.knobs() == ""                                            # everything back at its default ...
+            c2.configure("ML_PI", "2"); c2.configure("RS", "generic")
+            assert c2.knobs() == "ML_PI=2 RS=1"                                # ... and what is not is named (measurement scripts echo it)
+            c2.configure("ML_PI", None); c2.configure("RS", None)
             for key, val in (("NO_SUCH_KNOB", "1"), ("SCATTER_B", "100"), ("ML_THREADS", "1000"), ("APPLY", "sideways")):
                 with pytest.raises(api.LdpcAmdError):
                     c2.configure(key, val)
