@@ -318,13 +318,15 @@ static int register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_pt
     std::vector<uint8_t> ell_logc((size_t)degpad * mpad, 0), ell_coef((size_t)degpad * mpad, 0);
     std::vector<uint32_t> ell_pk((size_t)degpad * mpad, 0xFFFFu);
     std::vector<uint16_t> rx_off((size_t)degpad * mpad, (uint16_t)(2 * n));   // (n <= 32767 for the relaxation kernel: checked at launch)
+    std::vector<uint8_t> rx_logc((size_t)degpad * mpad, 0);
     for (int r = 0; r < m; r++)
         for (uint32_t e = row_ptr[r], t = 0; e < row_ptr[r + 1]; e++, t++) {
             ell_col[(size_t)t * mpad + r] = cols[e];
             ell_logc[(size_t)t * mpad + r] = gf.log[hc->coefs[e]];
             ell_coef[(size_t)t * mpad + r] = hc->coefs[e];
             ell_pk[(size_t)t * mpad + r] = (uint32_t)cols[e] | ((uint32_t)gf.log[hc->coefs[e]] << 16);
-            rx_off[(size_t)t * mpad + r] = (uint16_t)(2 * cols[e]);
+            rx_off[((size_t)(r >> 6) * degpad + t) * 64 + (r & 63)] = (uint16_t)(2 * cols[e]);
+            rx_logc[((size_t)(r >> 6) * degpad + t) * 64 + (r & 63)] = gf.log[hc->coefs[e]];
         }
 
     // static encode schedule: row i solves column k+i (triangle form) once the parity symbols among its other
@@ -575,7 +577,7 @@ static int register_code(ldpc_amd_ctx *ctx, int n, int k, const uint32_t *row_pt
     int rc;
     if ((rc = upload(ctx, hc, hc->row_ptr, &d.row_ptr)) || (rc = upload(ctx, hc, edges, &d.edges)) ||
         (rc = upload(ctx, hc, ell_col, &d.ell_col)) || (rc = upload(ctx, hc, ell_logc, &d.ell_logc)) ||
-        (rc = upload(ctx, hc, ell_coef, &d.ell_coef)) || (rc = upload(ctx, hc, ell_pk, &d.ell_pk)) || (rc = upload(ctx, hc, rx_off, &d.rx_off)) || (rc = upload(ctx, hc, cell, &d.cell)) ||
+        (rc = upload(ctx, hc, ell_coef, &d.ell_coef)) || (rc = upload(ctx, hc, ell_pk, &d.ell_pk)) || (rc = upload(ctx, hc, rx_off, &d.rx_off)) || (rc = upload(ctx, hc, rx_logc, &d.rx_logc)) || (rc = upload(ctx, hc, cell, &d.cell)) ||
         (rc = upload(ctx, hc, enc_src, &d.enc_src)) || (rc = upload(ctx, hc, enc_order, &d.enc_order)) || (rc = upload(ctx, hc, enc_invc, &d.enc_invc)) ||
         (rc = upload(ctx, hc, enc_steps, &d.enc_steps)) || (rc = upload(ctx, hc, enc_lvlend, &d.enc_lvlend)) ||
         (rc = upload(ctx, hc, enc_lst, &d.enc_lst)) || (rc = upload(ctx, hc, enc_lst_off, &d.enc_lst_off)) ||

@@ -46,7 +46,9 @@ struct DevCode {
     const uint8_t *ell_logc;  // [degpad][mpad]  log(coef)
     const uint8_t *ell_coef;  // [degpad][mpad]  coef
     const uint32_t *ell_pk;   // [degpad][mpad]  col | log(coef) << 16 (S = 1 kernel: one LDS read per neighbour)
-    const uint16_t *rx_off;   // [degpad][mpad]  col * 2, padding n * 2: byte offset of the neighbour's 16-bit key word (peel_relax.inc)
+    const uint16_t *rx_off;   // [mpad / 64][degpad][64]  col * 2, padding n * 2: byte offset of the neighbour's 16-bit key word (peel_relax.inc;
+                              // chunk-major: the entries of a check are a compile-time stride apart, the lanes of a chunk read consecutive ones)
+    const uint8_t *rx_logc;   // [mpad / 64][degpad][64]  log(coef), same order
     const uint8_t *enc_invc;  // [m]  inverse of the coefficient each static encode step divides by
     const uint32_t *cell;     // [n][1 << cdw_shift]  column lists: check | coef << 16, 0xFFFFFFFF = none
     int cdw_shift;            // log2 of the padded column-list width (>= maxcoldeg)

@@ -2163,7 +2163,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
         if (!relax_ok) return 0;
         RelaxArgs ra{};
         ra.n = cd.n; ra.k = cd.k; ra.m = cd.m; ra.mpad = cd.mpad; ra.logM = logM;
-        ra.rx_off = cd.rx_off; ra.ell_logc = cd.ell_logc; ra.ell_coef = cd.ell_coef;
+        ra.rx_off = cd.rx_off; ra.ell_logc = cd.rx_logc; ra.ell_coef = cd.ell_coef;
         ra.nframes = nf; ra.sym = d.sym; ra.erased = d.erased; ra.max_sweeps = d.max_sweeps; ra.do_ml = mode == 1 ? 0 : d.do_ml;
         ra.out = d.out; ra.sweeps = d.sweeps; ra.residual = d.residual; ra.status = d.status; ra.residual_sys = d.residual_sys;
         ra.ml_list = (int32_t *)ctx->mllist.p; ra.ml_state = (uint8_t *)ctx->mlstate.p; ra.err = ctx->dev_err_host;

@@ -69,7 +69,7 @@ int main(int argc, char **argv)
     const double per = (bursty || parity) ? 0.0 : atof(argv[4]);
     const int max_sweeps = atoi(argv[5]);
     int wpb_arg = argc > 6 ? atoi(argv[6]) : 0;
-    const int gt = argc > 7 ? atoi(argv[7]) : 0, U = argc > 8 ? atoi(argv[8]) : 1, inner_max = argc > 9 ? atoi(argv[9]) : 0;
+    const int gt = argc > 7 ? atoi(argv[7]) : 0, U = argc > 8 ? atoi(argv[8]) : 1, inner_max = argc > 9 ? atoi(argv[9]) : 0, lab_stop = argc > 10 ? atoi(argv[10]) : 0;
 
     // GF(256), poly 0x171
     uint8_t lg[256] = {0}, ex[512];
@@ -94,8 +94,8 @@ int main(int argc, char **argv)
     std::vector<uint8_t> ell_logc((size_t)degpad * mpad, 0);
     for (int r = 0; r < m; r++)
         for (uint32_t e = row_ptr[r], t = 0; e < row_ptr[r + 1]; e++, t++) {
-            ell_col[(size_t)t * mpad + r] = (uint16_t)(cols[e] * 2);
-            ell_logc[(size_t)t * mpad + r] = lg[coefs[e]];
+            ell_col[((size_t)(r >> 6) * degpad + t) * 64 + (r & 63)] = (uint16_t)(cols[e] * 2);     // chunk-major: [chunk][slot][check in chunk]
+            ell_logc[((size_t)(r >> 6) * degpad + t) * 64 + (r & 63)] = lg[coefs[e]];
         }
 
     // frames: codewords (systematic encode, ErasureCodes_NonBinaryLDPCSim.m:173-182) with erasures; every 7th frame gets a corrupted
@@ -250,7 +250,7 @@ int main(int argc, char **argv)
         printf("\n");
     }
     // timing
-    a.dbg_fire = nullptr; a.dbg_evals = nullptr;
+    a.dbg_fire = nullptr; a.dbg_evals = nullptr; a.lab_stop = lab_stop;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     launch();
