@@ -94,6 +94,7 @@ static const KnobDesc kKnobs[] = {
     LDPC_KNOB_INT("PEEL_WPB", peel_wpb, x >= 0 && x <= 16),
     LDPC_KNOB_INT("PEEL_GT", peel_gt, x >= -1 && x <= 1),
     LDPC_KNOB_INT("PEEL_RELAX", peel_relax, x == 0 || x == 1),
+    LDPC_KNOB_INT("ENC_PERSIST", enc_persist, x == 0 || x == 1),
     LDPC_KNOB_INT("ML_SOLVE", ml_solve, x >= 0 && x <= 2),
     LDPC_KNOB_INT("ML_DBG", ml_dbg, x >= 0),
     LDPC_KNOB_INT("ML_SOLVE_B", ml_solve_b, x == 16 || x == 32 || x == 64 || x == 128),
@@ -815,7 +816,7 @@ void ldpc_amd_cleanup(ldpc_amd_ctx *ctx)
         if (r->d_pt) (void)hipFree(r->d_pt);
         delete r;
     }
-    Scratch *all[] = {&ctx->sched, &ctx->mlws, &ctx->mlstate, &ctx->mlops, &ctx->mlrec, &ctx->mllist, &ctx->biglist, &ctx->stage_in, &ctx->stage_er,
+    Scratch *all[] = {&ctx->sched, &ctx->mlws, &ctx->mlstate, &ctx->mlops, &ctx->mlrec, &ctx->mllist, &ctx->biglist, &ctx->encctr, &ctx->stage_in, &ctx->stage_er,
                       &ctx->stage_out, &ctx->stage_i32, &ctx->schedpull, &ctx->schedlists, &ctx->rsws, &ctx->rsbad, &ctx->fpga_erased, &ctx->fpga_stats};
     for (Scratch *s : all) scratch_free(*s);
     for (auto &v : ctx->prof_events)

@@ -115,6 +115,7 @@ struct Knobs {
     int scatter_t2b = 256;       // SCATTER_T2B: bytes of every row per TIER-2 workgroup (256: one workgroup per CU; 128: two)
     int peel_wpb = 0;            // PEEL_WPB: frames per peel workgroup (0 = auto)
     int peel_gt = -1;            // PEEL_GT: S = 1 kernel reads the code tables from global memory (-1 = auto)
+    int enc_persist = 1;         // ENC_PERSIST: packet encoder as persistent workgroups (tables and lists set up once per workgroup); 0: one workgroup per (frame, slice)
     int peel_relax = 1;          // PEEL_RELAX: S = 1 decode (and the pattern-only runs) by time-stamp relaxation (peel_relax.inc); 0: the serial per-solve loop
     int ml_solve = 1;            // ML_SOLVE: 1 solve schedules + solve kernel, 0 solve inside the ML kernel, 2 emit only (diagnostic)
     int ml_dbg = 0;              // ML_DBG: diagnostic build only
@@ -175,6 +176,7 @@ struct ldpc_amd_ctx {
     ldpc_amd::Scratch mlrec;    // packets: [ML-list slot][8] u32 schedule records
     ldpc_amd::Scratch mllist;   // [1 + nframes] int32: count, frame ids
     ldpc_amd::Scratch biglist;  // [1 + nframes] int32: frames with many steps (scatter tier 2)
+    ldpc_amd::Scratch encctr;   // persistent encoder: item counter, workgroups done (self-resetting)
     ldpc_amd::Scratch stage_in, stage_er, stage_out, stage_i32;  // host-pointer staging
     bool ml_head_valid = false;                   // a packet-mode ML stage has copied its demand there at least once
     unsigned long long *ml_head_host = nullptr;   // pinned: arena words the last packet-mode ML stage asked for

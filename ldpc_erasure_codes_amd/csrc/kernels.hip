@@ -696,9 +696,15 @@ __device__ __forceinline__ void stream_store16(uint8_t *p, const U4 &v)
     }
 }
 
-template <int LPR, int R, bool NT, bool INPLACE, int WPE = 4>
+// PERSIST (encoder only: ldpc_scatter_static_kernel): a workgroup encodes many (frame, slice) items, and everything its LDS holds that
+// depends on the CODE alone -- multiply tables, the schedule's tables, the level phase's lists -- is set up by the first item (warm = false)
+// and kept; a warm item zeroes its accumulators and starts streaming.
+template <int LPR, int R, bool NT, bool INPLACE, int WPE = 4, bool PERSIST = false, bool WARM = false>
 __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned char *smem, const int64_t f, const int sl)
 {
+    constexpr bool warm = WARM;
+    // (the persistent form is the encoder's: the decoder's paths fold away in its instantiations)
+    const bool is_static = PERSIST ? true : (a.static_sched != 0);
     constexpr int RPW = 64 / LPR;              // row pieces per wave instruction
     constexpr int KQ = (16 + LPR - 1) / LPR;   // edge words held per lane (maxcoldeg <= 16)
     constexpr int B = 16 * LPR;                // bytes of every row handled by this workgroup (R pieces in flight per lane)
@@ -736,16 +742,16 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
 
     LDPC_STAMP_INIT;
 #ifdef LDPC_AMD_MLDBG
-    const int nsteps = a.static_sched ? cd.m : ((a.dbg & 32768) ? min((int)a.sched_hdr[2 * f], a.nslots) : (int)a.sched_hdr[2 * f]);
+    const int nsteps = is_static ? cd.m : ((a.dbg & 32768) ? min((int)a.sched_hdr[2 * f], a.nslots) : (int)a.sched_hdr[2 * f]);
 #else
-    const int nsteps = a.static_sched ? cd.m : (int)a.sched_hdr[2 * f];
+    const int nsteps = is_static ? cd.m : (int)a.sched_hdr[2 * f];
 #endif
-    const bool grouped = a.static_sched && a.enc_group;
-    const uint32_t hdr1 = a.static_sched ? 0u : a.sched_hdr[2 * f + 1];   // levels | bit 31: they come in pairs (peel_relax.inc mode 2)
-    const int nlev = a.static_sched ? (grouped ? cd.encg_nlevels : cd.enc_nlevels) : (int)(hdr1 & 0x7FFFFFFFu);
-    const uint32_t *gs = a.static_sched ? (grouped ? cd.encg_steps : cd.enc_steps) : a.sched_steps + f * cd.m;
-    const uint16_t *gle = a.static_sched ? (grouped ? cd.encg_lvlend : cd.enc_lvlend) : a.sched_lvlend + f * (cd.m + 1);
-    const uint8_t *gic = a.static_sched ? (grouped ? cd.encg_invc : cd.enc_invc) : a.sched_invc + f * cd.m;
+    const bool grouped = is_static && a.enc_group;
+    const uint32_t hdr1 = is_static ? 0u : a.sched_hdr[2 * f + 1];   // levels | bit 31: they come in pairs (peel_relax.inc mode 2)
+    const int nlev = is_static ? (grouped ? cd.encg_nlevels : cd.enc_nlevels) : (int)(hdr1 & 0x7FFFFFFFu);
+    const uint32_t *gs = is_static ? (grouped ? cd.encg_steps : cd.enc_steps) : a.sched_steps + f * cd.m;
+    const uint16_t *gle = is_static ? (grouped ? cd.encg_lvlend : cd.enc_lvlend) : a.sched_lvlend + f * (cd.m + 1);
+    const uint8_t *gic = is_static ? (grouped ? cd.encg_invc : cd.enc_invc) : a.sched_invc + f * cd.m;
     const uint8_t *erf = a.erased ? a.erased + f * (int64_t)n : nullptr;
     // Set-up costs one global-memory latency: everything that comes from global memory (this thread's steps, erasure
     // flags, level offsets, multiply tables) is requested first, the LDS is initialised while the loads are in flight.
@@ -755,8 +761,8 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
 #pragma unroll
     for (int u = 0; u < SPT; u++) {
         const int s = tid + u * nthr;
-        stp[u] = s < nsteps ? gs[s] : 0u;
-        siv[u] = s < nsteps ? (uint32_t)gic[s] : 0u;
+        stp[u] = (s < nsteps && !(PERSIST && warm)) ? gs[s] : 0u;
+        siv[u] = (s < nsteps && !(PERSIST && warm)) ? (uint32_t)gic[s] : 0u;
     }
 #pragma unroll
     for (int u = 0; u < EPT; u++) {
@@ -769,8 +775,8 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     // Paired levels (a.pairs: the schedule comes from peel_relax.inc mode 2): the steps of a group's second half pull the raw accumulators
     // of their first-half inputs; their pull entries (two words) and every step's level (u16) go behind the lists when there is room,
     // else the frame runs its levels one by one (they are a valid levelling on their own) without pulls and exclusions.
-    const bool pairs_f = !a.static_sched && a.pairs && (hdr1 >> 31) && a.xl_setup && (int64_t)nsteps * (B + 4 * cdw + 10) + 16 <= (int64_t)a.nslots * B;
-    const bool lds_lists = !a.static_sched && (pairs_f || (int64_t)nsteps * (B + 4 * cdw) <= (int64_t)a.nslots * B);
+    const bool pairs_f = !is_static && a.pairs && (hdr1 >> 31) && a.xl_setup && (int64_t)nsteps * (B + 4 * cdw + 10) + 16 <= (int64_t)a.nslots * B;
+    const bool lds_lists = !is_static && (pairs_f || (int64_t)nsteps * (B + 4 * cdw) <= (int64_t)a.nslots * B);
     uint32_t *slist = reinterpret_cast<uint32_t *>(acc + (size_t)nsteps * B);   // [nsteps][cdw]
     uint32_t *plist = slist + (size_t)nsteps * cdw;                              // [nsteps][2] pull entries (pairs_f)
     uint16_t *slev = reinterpret_cast<uint16_t *>(plist + (size_t)nsteps * 2);   // [nsteps] level of the step (pairs_f)
@@ -802,17 +808,21 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
             }
         }
     }
+    if (!(PERSIST && warm)) {
     for (int i = tid; i < 2048; i += nthr) mt[i] = c_mul3[i];
 #ifdef LDPC_AMD_MLDBG
     for (int i = tid; i <= nlev; i += nthr) lvlend[i] = (uint16_t)min((int)gle[i], nsteps);
 #else
     for (int i = tid; i <= nlev; i += nthr) lvlend[i] = gle[i];
 #endif
-    if (!a.static_sched)   // (the encoder's lists are in slot form already: it has no check -> slot table)
+    }
+    if (!is_static)   // (the encoder's lists are in slot form already: it has no check -> slot table)
         for (int i = tid; i < (cd.m + 1) / 2; i += nthr) reinterpret_cast<uint32_t *>(soc)[i] = 0xFFFFFFFFu;
     if (tid < 2) reinterpret_cast<int *>(smem + a.lds_rowctr)[tid] = 0;   // [0] row-batch counter of the streaming phase, [1] received rows
     for (int i = tid; i < nsteps * LPR; i += nthr) reinterpret_cast<U4 *>(acc)[i] = U4{0, 0, 0, 0};
     // row kinds: 1 received, 2 erased and never solved (written as 0), 0 erased and solved in phase B (set below)
+    // (PERSIST: the encoder's source rows are all received -- its stream does not consult the table, whose place the lists of the level phase keep)
+    if (!PERSIST) {
 #pragma unroll
     for (int u = 0; u < EPT; u++) {
         const int j = tid + u * nthr;
@@ -820,13 +830,14 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     }
     for (int j = tid + EPT * nthr; j < n; j += nthr)
         rk[j] = (erf ? (erf[j] != 0) : (j >= a.in_rows)) ? (uint8_t)2 : (uint8_t)1;
+    }
     __syncthreads();
     auto put_step = [&](int s, uint32_t step, uint32_t iv) {
         const uint32_t row = step & 0xFFFFu, t = step >> 16;
         tgt[s] = (uint16_t)t;
-        if (!a.static_sched) soc[row] = (uint16_t)s;
+        if (!is_static) soc[row] = (uint16_t)s;
         invc[s] = (uint8_t)iv;
-        rk[t] = 0;
+        if (!PERSIST) rk[t] = 0;
     };
     auto put_pull = [&](int s, uint32_t lv, uint32_t p0, uint32_t p1) {
         // a pull entry leaves as (LDS address of the pulled accumulator slice | coef << 24), like the scatter entries
@@ -834,6 +845,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         plist[2 * s] = p0 == 0xFFFFFFFFu ? p0 : (((uint32_t)kAccOff + (p0 & 0x00FFFFFFu) * (uint32_t)B) | (p0 & 0xFF000000u));
         plist[2 * s + 1] = p1 == 0xFFFFFFFFu ? p1 : (((uint32_t)kAccOff + (p1 & 0x00FFFFFFu) * (uint32_t)B) | (p1 & 0xFF000000u));
     };
+    if (!(PERSIST && warm)) {
 #pragma unroll
     for (int u = 0; u < SPT; u++) {
         const int s = tid + u * nthr;
@@ -843,6 +855,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     for (int s = tid + SPT * nthr; s < nsteps; s += nthr) {
         put_step(s, gs[s], gic[s]);
         if (pairs_f) { const uint32_t *r_ = gpl + ((size_t)f * cd.m + s) * 4; put_pull(s, r_[0], r_[1], r_[2]); }
+    }
     }
     if (lds_lists) {
         // The lists go to LDS TRANSLATED (check -> LDS address of the step's accumulator slice | coef << 24, the form the turns of
@@ -883,16 +896,16 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     // handles at once then have the same number of edges, so no lane group idles while another finishes its row (with
     // rows in index order a pass takes max-over-four turns: 2.4 for 1.3 edges per row at 10 % erasures), and the rows
     // that feed nothing come last and skip the multiply set-up altogether.
-    const bool sorted_mode = a.dyn_rows == 3 && n <= EPT * nthr && !a.static_sched && cdw <= 16;
+    const bool sorted_mode = a.dyn_rows == 3 && n <= EPT * nthr && !is_static && cdw <= 16;
     // Windowed sorted list (a.dyn_rows == 4): the same ordering INSIDE windows of 64 consecutive rows (the rows one wavefront
     // of the set-up holds), windows in index order: the pieces of a pass still take about the same number of turns, and a pass
     // stays inside a 64 KB stretch of the frame instead of hopping all over it (what the global order lost to).
-    const bool win_mode = a.dyn_rows == 4 && n <= EPT * nthr && !a.static_sched && cdw <= 16;
+    const bool win_mode = a.dyn_rows == 4 && n <= EPT * nthr && !is_static && cdw <= 16;
     // Encoder (static schedule): the list is the code's source symbols in the order of their column degree, prepared by the
     // host (DevCode::enc_order) -- same effect as the sorted mode, no per-frame work.  Measured slower than index order (the
     // list look-ups and the lost DRAM locality cost more than the balanced turns save): only with LDPC_AMD_ENC_LIST=1.
-    const bool static_list = a.static_sched && a.enc_list && a.lds_soc_bytes >= 2 * a.in_rows;
-    const bool list_mode = ((a.dyn_rows == 2 || sorted_mode || win_mode) && n <= EPT * nthr && !a.static_sched) || static_list;
+    const bool static_list = !PERSIST && is_static && a.enc_list && a.lds_soc_bytes >= 2 * a.in_rows;
+    const bool list_mode = ((a.dyn_rows == 2 || sorted_mode || win_mode) && n <= EPT * nthr && !is_static) || static_list;
     if (static_list) {
         for (int i = tid; i < a.in_rows; i += nthr) rlist[i] = cd.enc_order[i];
         __syncthreads();
@@ -996,8 +1009,8 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     auto in_row = [&](int j) { return fin0 + (__umul24((uint32_t)j, S32) + lo16); };
     auto out_row = [&](int j) { return fout0 + (__umul24((uint32_t)j, S32) + lo16); };
     // H's static column lists (check | coef << 16); the encoder's are already in (slot | coef << 16) form
-    const uint32_t *spad = a.static_sched ? (grouped ? cd.encg_src : cd.enc_src) : cd.cell;
-    const bool translate = !a.static_sched;
+    const uint32_t *spad = is_static ? (grouped ? cd.encg_src : cd.enc_src) : cd.cell;
+    const bool translate = !is_static;
 
     // multiplies v into the accumulators of the steps that symbol j feeds: ew = the symbol's list, entry t held by
     // lane (t % LPR) of the group, 0xFFFFFFFF = no entry.  Every group walks the set bits of its own validity mask.
@@ -1077,12 +1090,12 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     };
     // rows the streaming phase walks: all n for the decoder; the encoder's parity rows (j >= k) are all produced by the level
     // phase, so its stream ends at k (a quarter of the (2040,1530) rows)
-    const int nstream = a.static_sched ? a.in_rows : n;
+    const int nstream = is_static ? a.in_rows : n;
     auto fetch = [&](int j0, RowBatch &b) {
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int j = j0 + r * RPW + g;
-            const int kd = (j < nstream) ? (int)rk[j] : 0;
+            const int kd = (j < nstream) ? (PERSIST ? 1 : (int)rk[j]) : 0;
             b.kind[r] = kd;
             b.v[r] = U4{0, 0, 0, 0};
 #pragma unroll
@@ -1188,7 +1201,9 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     const uint8_t *g_coef = smem + a.lds_soc + 2 * gent2;
     const uint16_t *g_off = reinterpret_cast<const uint16_t *>(smem + a.lds_soc + 3 * gent2);
     const uint8_t *g_np = smem + a.lds_soc + 3 * gent2 + 2 * ((cd.m + 8) & ~7);
-    if (grouped) {
+    if (PERSIST && warm) {
+        // (the lists are in place since the workgroup's first item)
+    } else if (grouped) {
         uint16_t *ws = reinterpret_cast<uint16_t *>(smem + a.lds_soc);
         uint8_t *wc = smem + a.lds_soc + 2 * gent2;
         uint16_t *wo = reinterpret_cast<uint16_t *>(smem + a.lds_soc + 3 * gent2);
@@ -1201,7 +1216,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         for (int i = tid; i <= nsteps; i += nthr) wo[i] = cd.encg_ent_off[i];
         for (int i = tid; i < nsteps; i += nthr) wn[i] = cd.encg_npull[i];
         __syncthreads();
-    } else if (a.static_sched && a.enc_clist) {
+    } else if (is_static && a.enc_clist) {
         uint32_t *cw_ = reinterpret_cast<uint32_t *>(smem + a.lds_soc);
         uint16_t *co_ = reinterpret_cast<uint16_t *>(smem + a.lds_soc + 4 * cd.enc_lst_n);
         for (int i = tid; i < cd.enc_lst_n; i += nthr) cw_[i] = cd.enc_lst[i];
@@ -1302,15 +1317,32 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
                                                : *reinterpret_cast<const U4 *>(acc + (size_t)su[u] * B + gl * 16);
                     npmax = max(npmax, np[u]);
                 }
-                for (uint32_t i = 0; __any(i < npmax); i++) {
+                // The pulls PQ at a time: their list entries first, then the pulled accumulators and the coefficient tables, then the
+                // multiply-accumulates -- three LDS round trips per PQ pulls instead of three per pull (an entry past the end of the
+                // step's list pulls the step's own accumulator with coefficient 0: no branch in the batch).
+                constexpr int PQ = WPE >= 8 ? 2 : 4;
+                for (uint32_t i = 0; __any(i < npmax); i += PQ) {
 #pragma unroll
-                    for (int u = 0; u < U; u++)
-                        if (i < np[u]) {
-                            const uint32_t sl_ = g_slot[o0[u] + i], cf = g_coef[o0[u] + i];
-                            const U4 src = kSplit ? lds_read16_split(acc + (size_t)sl_ * B, gl, B / 2)
-                                                  : *reinterpret_cast<const U4 *>(acc + (size_t)sl_ * B + gl * 16);
-                            gfmac16(a16[u], lds_multab(mt, cf), src);
+                    for (int u = 0; u < U; u++) {
+                        uint32_t sl_[PQ], cf[PQ];
+#pragma unroll
+                        for (int q = 0; q < PQ; q++) {
+                            const bool v = i + (uint32_t)q < np[u];
+                            const uint32_t e = o0[u] + (v ? i + (uint32_t)q : 0u);
+                            sl_[q] = g_slot[e]; cf[q] = g_coef[e];
+                            if (!v) { sl_[q] = on[u] ? su[u] : 0u; cf[q] = 0u; }
                         }
+                        U4 src[PQ];
+                        MulTab tb[PQ];
+#pragma unroll
+                        for (int q = 0; q < PQ; q++) {
+                            src[q] = kSplit ? lds_read16_split(acc + (size_t)sl_[q] * B, gl, B / 2)
+                                            : *reinterpret_cast<const U4 *>(acc + (size_t)sl_[q] * B + gl * 16);
+                            tb[q] = lds_multab(mt, cf[q]);
+                        }
+#pragma unroll
+                        for (int q = 0; q < PQ; q++) gfmac16(a16[u], tb[q], src[q]);
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < U; u++)
@@ -1333,7 +1365,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         }
     };
     if (grouped) phase_g();
-    else if (a.static_sched && a.enc_clist) phase_b(std::integral_constant<int, 2>{});
+    else if (is_static && a.enc_clist) phase_b(std::integral_constant<int, 2>{});
     else if (lds_lists) phase_b(std::integral_constant<int, 1>{});
     else phase_b(std::integral_constant<int, 0>{});
     LDPC_STAMP(15);  // scatter: level phase
@@ -1383,6 +1415,37 @@ __global__ __launch_bounds__(1024, WPE) void ldpc_scatter_big_kernel(ScatterArgs
         const int it = *slot;
         if (it >= items) break;
         scatter_frame<LPR, R, NT, INPLACE, WPE>(a, smem, a.big_list[2 + it / a.nslices], (int)(it % a.nslices));
+    }
+}
+
+// Encoder, persistent form: the schedule is the CODE's, so a workgroup sets its tables up once and then encodes (frame, slice) items
+// handed out through a device counter (first come, first served: with a fixed stride the slowest CU's workgroups finish 7 % late).
+// The counter resets itself: the last workgroup to find it exhausted zeroes it for the next launch of this context.
+template <int LPR, int R, bool NT, int WPE>
+__global__ __launch_bounds__(1024, WPE) void ldpc_scatter_static_kernel(ScatterArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int items = (int)(a.nframes * a.nslices);
+    int *slot = reinterpret_cast<int *>(smem + a.lds_rowctr) + 2;   // (ints 0 / 1 of the region are re-initialised by every item)
+    auto next_item = [&]() -> int {
+        __syncthreads();   // (also: the last level of the item before is through with the accumulators)
+        if (threadIdx.x == 0) *slot = atomicAdd(&a.big_list[0], 1);
+        __syncthreads();
+        return *slot;
+    };
+    // (the first item, which sets the tables up, and the warm ones are two instantiations: a run-time flag kept both sets of values alive
+    // across the loop -- 108 spilled registers against 12 of the one-item kernel)
+    int it = next_item();
+    if (it < items) {
+        scatter_frame<LPR, R, NT, false, WPE, true, false>(a, smem, it / a.nslices, it % a.nslices);
+        while ((it = next_item()) < items) scatter_frame<LPR, R, NT, false, WPE, true, true>(a, smem, it / a.nslices, it % a.nslices);
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&a.big_list[1], 1) == (int)gridDim.x - 1) {   // every workgroup has made its last request
+            a.big_list[0] = 0; a.big_list[1] = 0;
+            __threadfence();
+        }
     }
 }
 
@@ -1698,6 +1761,33 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
     // tier 1
     sa.tcap = p.tcap; sa.nslots = p.tcap; sa.big_list = nullptr;
     scatter_set_lds(sa, p, p.tcap);
+    if constexpr (LPR >= 8) {
+        // Encoder: the persistent form (ENC_PERSIST; not with ENC_LIST, whose row list lives where the kept lists do)
+        if (sa.static_sched && kn.enc_persist != 0 && !sa.enc_list && !sa.inplace && (sa.enc_group || sa.enc_clist)) {
+            const int per_cu = std::max(1, std::min(p.two_tier ? 2 : 1, kLdsMax / std::max(1, p.lds1)));
+            const dim3 gp((unsigned)std::min<int64_t>((int64_t)grid.x, (int64_t)ctx->sm_count * per_cu));
+            if (!ctx->encctr.p) {   // the item counter (self-resetting: zeroed once)
+                int rc_e;
+                if ((rc_e = scratch_reserve(ctx, ctx->encctr, 64))) return rc_e;
+                LDPC_HIP_TRY(ctx, hipMemsetAsync(ctx->encctr.p, 0, 64, ctx->stream));
+            }
+            sa.big_list = (int32_t *)ctx->encctr.p;
+            char nm[96];
+            snprintf(nm, sizeof(nm), "ldpc_scatter_static_kernel<%d, %d, %s, %d>", LPR, R, nt ? "true" : "false", p.two_tier ? 8 : 4);
+            ctx->prof_names[LDPC_AMD_PROF_APPLY] = nm;
+#define LDPC_SCATTER_PS(NTV, WPE)                                                                            \
+    {                                                                                                        \
+        auto kfn = ldpc_scatter_static_kernel<LPR, R, NTV, WPE>;                                             \
+        LDPC_HIP_TRY(ctx, allow_max_lds(reinterpret_cast<const void *>(kfn)));                               \
+        hipLaunchKernelGGL(kfn, gp, dim3(THREADS), (size_t)p.lds1, ctx->stream, sa);                         \
+    }
+            if (p.two_tier) { if (nt) LDPC_SCATTER_PS(true, 8) else LDPC_SCATTER_PS(false, 8) }
+            else { if (nt) LDPC_SCATTER_PS(true, 4) else LDPC_SCATTER_PS(false, 4) }
+#undef LDPC_SCATTER_PS
+            LDPC_HIP_TRY(ctx, hipGetLastError());
+            return LDPC_AMD_OK;
+        }
+    }
 #define LDPC_SCATTER_T1(NTV, WPE, IPV)                                                                         \
     {                                                                                                        \
         auto kfn = ldpc_scatter_kernel<LPR, R, NTV, WPE, IPV>;                                                    \
