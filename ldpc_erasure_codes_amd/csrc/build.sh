@@ -15,7 +15,7 @@ echo "$FLAGS" > "$OBJ/flags.new"
 if ! cmp -s "$OBJ/flags.new" "$OBJ/flags" 2>/dev/null; then rm -f "$OBJ"/*.o; mv "$OBJ/flags.new" "$OBJ/flags"; fi
 COMMON="$HERE/internal.h $ROOT/include/ldpc_erasure_amd.h $ROOT/include/ldpc_erasure_amd_synth.h $ROOT/include/ldpc_erasure_amd_wire.h $ROOT/include/ldpc_erasure_amd_multi.h"
 declare -A DEPS=(
-  [kernels.hip]="$HERE/gf256_dev.h $HERE/ml_kernel.inc $HERE/ml_pi.inc $HERE/rs_kernels.inc $HERE/fpga_kernels.inc"
+  [kernels.hip]="$HERE/gf256_dev.h $HERE/peel_relax.inc $HERE/ml_kernel.inc $HERE/ml_pi.inc $HERE/rs_kernels.inc $HERE/fpga_kernels.inc"
   [api.cpp]="$HERE/builtin_codes_gen.inc"
   [wire.cpp]=""
   [multi.hip]=""

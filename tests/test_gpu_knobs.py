@@ -29,6 +29,7 @@ KNOBS = [
     ("LDPC_AMD_ENC_LIST", ["1"]),
     ("LDPC_AMD_ENC_CLIST", ["0"]),
     ("LDPC_AMD_ENC_GROUP", ["0"]),
+    ("LDPC_AMD_ENC_PERSIST", ["0"]),
     ("LDPC_AMD_PEEL_RELAX", ["0"]),
     ("LDPC_AMD_PEEL_GT", ["0", "1"]),
     ("LDPC_AMD_PEEL_WPB", ["1", "4", "16"]),

@@ -31,6 +31,49 @@ def _random_triangle_code(rng, n, k, deg):
     return codes.Code(n, k, np.array(row_ptr, dtype=np.uint32), np.array(cols, dtype=np.uint16), np.array(coefs, dtype=np.uint8))
 
 
+@pytest.mark.parametrize("code_ind", [1, 3])
+def test_persistent_encoder_equals_the_one_item_kernel_and_the_oracle(oracle, code_ind):
+    """ENC_PERSIST = 1 (the default: persistent workgroups that set the code's tables up once and take (frame, slice) items from a
+    self-resetting device counter) against ENC_PERSIST = 0 (one workgroup per item) and the oracle's row-by-row encoder
+    (Matlab/ErasureCodes_NonBinaryLDPCSim.m:173-182): batches smaller and larger than the grid, call after call on one context (the
+    counter must come back to zero), grouped and plain static schedules, with an S = 1 encode and a decode in between."""
+    if not codes.have_builtin(code_ind):
+        pytest.skip("fixture of this code not present")
+    code = codes.load_builtin(code_ind)
+    oc = oracle.OracleCode(code)
+    with api.Context(0) as ctx:
+        h = ctx.load_builtin_code(code_ind, codes.DEFAULT_COEF_SEED[code_ind])
+        for group in ("1", "0"):
+            ctx.configure("ENC_GROUP", group)
+            for S, F in ((1024, 3), (128, 1), (256, 70), (1024, 130), (128, 7)):
+                src = synth.source(900 + S + F, 0, F, code.k, S)
+                ctx.configure("ENC_PERSIST", "1")
+                cw = ctx.encode(h, src)
+                cw_again = ctx.encode(h, src)
+                ctx.configure("ENC_PERSIST", "0")
+                cw0 = ctx.encode(h, src)
+                assert np.array_equal(cw, cw0), (code_ind, group, S, F)
+                assert np.array_equal(cw_again, cw0), (code_ind, group, S, F)
+                for f in (0, F // 2, F - 1):
+                    assert np.array_equal(cw[f], oc.encode(src[f])), (code_ind, group, S, F, f)
+            ctx.configure("ENC_PERSIST", None)
+            # other kernels of the context in between, then the persistent encoder again
+            s1 = synth.source(77, 0, 5, code.k, 1)[:, :, 0]
+            c1 = ctx.encode(h, s1)
+            assert np.array_equal(c1[0], oc.encode(s1[0][:, None])[:, 0])
+            src = synth.source(901, 0, 4, code.k, 128)
+            cw = ctx.encode(h, src)
+            er = np.zeros((4, code.n), dtype=np.uint8)
+            er[:, ::9] = 1
+            rx = cw.copy()
+            rx[er.astype(bool)] = 0
+            res = ctx.decode(h, rx, er)
+            out = res[0] if isinstance(res, tuple) else res.out
+            assert np.array_equal(out, cw)
+            assert np.array_equal(ctx.encode(h, src), cw)
+        ctx.configure("ENC_GROUP", None)
+
+
 @pytest.mark.parametrize("code_ind", [1, 3, 2, 0])
 def test_grouped_encoder_equals_the_row_by_row_encoder(oracle, code_ind):
     if not codes.have_builtin(code_ind):
