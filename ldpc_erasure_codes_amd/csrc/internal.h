@@ -176,7 +176,8 @@ struct ldpc_amd_ctx {
     ldpc_amd::Scratch mlrec;    // packets: [ML-list slot][8] u32 schedule records
     ldpc_amd::Scratch mllist;   // [1 + nframes] int32: count, frame ids
     ldpc_amd::Scratch biglist;  // [1 + nframes] int32: frames with many steps (scatter tier 2)
-    ldpc_amd::Scratch encctr;   // persistent encoder: item counter, workgroups done (self-resetting)
+    ldpc_amd::Scratch encctr;   // persistent encoder: ring of (item counter, workgroups done) pairs, self-resetting
+    unsigned enc_launches = 0;
     ldpc_amd::Scratch stage_in, stage_er, stage_out, stage_i32;  // host-pointer staging
     bool ml_head_valid = false;                   // a packet-mode ML stage has copied its demand there at least once
     unsigned long long *ml_head_host = nullptr;   // pinned: arena words the last packet-mode ML stage asked for

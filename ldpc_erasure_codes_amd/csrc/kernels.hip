@@ -1766,12 +1766,16 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
         if (sa.static_sched && kn.enc_persist != 0 && !sa.enc_list && !sa.inplace && (sa.enc_group || sa.enc_clist)) {
             const int per_cu = std::max(1, std::min(p.two_tier ? 2 : 1, kLdsMax / std::max(1, p.lds1)));
             const dim3 gp((unsigned)std::min<int64_t>((int64_t)grid.x, (int64_t)ctx->sm_count * per_cu));
-            if (!ctx->encctr.p) {   // the item counter (self-resetting: zeroed once)
+            // the item counter: self-resetting, so zeroed once (synchronously: whatever stream the context is moved to later sees it);
+            // consecutive launches take consecutive counters of a ring, so two encodes in flight (a caller that changed the context's
+            // stream without waiting) do not share one
+            constexpr int kEncCtrs = 64;
+            if (!ctx->encctr.p) {
                 int rc_e;
-                if ((rc_e = scratch_reserve(ctx, ctx->encctr, 64))) return rc_e;
-                LDPC_HIP_TRY(ctx, hipMemsetAsync(ctx->encctr.p, 0, 64, ctx->stream));
+                if ((rc_e = scratch_reserve(ctx, ctx->encctr, (size_t)kEncCtrs * 64))) return rc_e;
+                LDPC_HIP_TRY(ctx, hipMemset(ctx->encctr.p, 0, (size_t)kEncCtrs * 64));
             }
-            sa.big_list = (int32_t *)ctx->encctr.p;
+            sa.big_list = (int32_t *)ctx->encctr.p + 16 * (ctx->enc_launches++ % kEncCtrs);
             char nm[96];
             snprintf(nm, sizeof(nm), "ldpc_scatter_static_kernel<%d, %d, %s, %d>", LPR, R, nt ? "true" : "false", p.two_tier ? 8 : 4);
             ctx->prof_names[LDPC_AMD_PROF_APPLY] = nm;
