@@ -72,6 +72,11 @@ def test_persistent_encoder_equals_the_one_item_kernel_and_the_oracle(oracle, co
             assert np.array_equal(out, cw)
             assert np.array_equal(ctx.encode(h, src), cw)
         ctx.configure("ENC_GROUP", None)
+        # more launches than the ring of item counters has entries: every counter must have reset itself
+        src = synth.source(902, 0, 3, code.k, 128)
+        ref = ctx.encode(h, src)
+        for _ in range(70):
+            assert np.array_equal(ctx.encode(h, src), ref)
 
 
 @pytest.mark.parametrize("code_ind", [1, 3, 2, 0])
