@@ -1761,7 +1761,7 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
     // tier 1
     sa.tcap = p.tcap; sa.nslots = p.tcap; sa.big_list = nullptr;
     scatter_set_lds(sa, p, p.tcap);
-    if constexpr (LPR >= 8) {
+    if constexpr (LPR >= 8 && R == 2) {   // (the shipped R; the SCATTER_R variants keep the one-item kernel: a third of the instantiations)
         // Encoder: the persistent form (ENC_PERSIST; not with ENC_LIST, whose row list lives where the kept lists do)
         if (sa.static_sched && kn.enc_persist != 0 && !sa.enc_list && !sa.inplace && (sa.enc_group || sa.enc_clist)) {
             const int per_cu = std::max(1, std::min(p.two_tier ? 2 : 1, kLdsMax / std::max(1, p.lds1)));
