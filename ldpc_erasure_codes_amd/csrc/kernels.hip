@@ -2290,14 +2290,18 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
             Lr.total = off + w_ * w;
         };
         auto best_plan = [&](bool gt_, int &w_best, RelaxLds &L_best) -> int {
-            int best_f = 0;
+            int best_f = 0, best_score = 0;
             const int wcap = kn.peel_wpb > 0 ? std::min(16, kn.peel_wpb) : 16;
             for (int w_ = 1; w_ <= wcap; w_++) {
                 RelaxLds t;
                 plan(gt_, w_, t);
                 if (t.total > kLdsMax) break;
-                const int frames = kn.peel_wpb > 0 ? w_ : std::min(32, (kLdsMax / t.total) * w_);
-                if (frames >= best_f) { best_f = frames; w_best = w_; L_best = t; }
+                const int wgs = kLdsMax / t.total;
+                const int frames = kn.peel_wpb > 0 ? w_ : std::min(32, wgs * w_);
+                // without tables to stage, two (or more) smaller workgroups per CU beat one large one holding a frame more
+                // ((4080,3060), 65536 frames: 6 x 2 frames 2.20 ms, 13 x 1 2.30 ms): a tenth of a bonus
+                const int score = frames * ((gt_ && wgs >= 2 && kn.peel_wpb <= 0) ? 11 : 10);
+                if (score >= best_score) { best_score = score; best_f = frames; w_best = w_; L_best = t; }
             }
             return best_f;
         };
