@@ -94,6 +94,8 @@ static const KnobDesc kKnobs[] = {
     LDPC_KNOB_INT("PEEL_WPB", peel_wpb, x >= 0 && x <= 16),
     LDPC_KNOB_INT("PEEL_GT", peel_gt, x >= -1 && x <= 1),
     LDPC_KNOB_INT("PEEL_RELAX", peel_relax, x == 0 || x == 1),
+    LDPC_KNOB_INT("SCATTER_T2P", scatter_t2p, x == 1 || x == 2 || x == 4 || x == 8),
+    LDPC_KNOB_INT("SCATTER_T2P_FORCE", scatter_t2p_force, x == 0 || x == 1),
     LDPC_KNOB_INT("ENC_PERSIST", enc_persist, x == 0 || x == 1),
     LDPC_KNOB_INT("ML_SOLVE", ml_solve, x >= 0 && x <= 2),
     LDPC_KNOB_INT("ML_DBG", ml_dbg, x >= 0),

@@ -116,6 +116,8 @@ struct Knobs {
     int peel_wpb = 0;            // PEEL_WPB: frames per peel workgroup (0 = auto)
     int peel_gt = -1;            // PEEL_GT: S = 1 kernel reads the code tables from global memory (-1 = auto)
     int enc_persist = 1;         // ENC_PERSIST: packet encoder as persistent workgroups (tables and lists set up once per workgroup); 0: one workgroup per (frame, slice)
+    int scatter_t2p = 2;         // SCATTER_T2P: tier 2 -- consecutive pieces of a frame per work item (1, 2, 4, 8): the frame's set-up is done once per item
+    int scatter_t2p_force = 0;   // SCATTER_T2P_FORCE: 1 = SCATTER_T2P pieces per item whatever the length of the tier-2 list (tests)
     int peel_relax = 1;          // PEEL_RELAX: S = 1 decode (and the pattern-only runs) by time-stamp relaxation (peel_relax.inc); 0: the serial per-solve loop
     int ml_solve = 1;            // ML_SOLVE: 1 solve schedules + solve kernel, 0 solve inside the ML kernel, 2 emit only (diagnostic)
     int ml_dbg = 0;              // ML_DBG: diagnostic build only

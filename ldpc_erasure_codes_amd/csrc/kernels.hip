@@ -613,6 +613,8 @@ struct ScatterArgs {
     const uint32_t *sched_lists;  // [nframes][m][cdw] the steps' column lists in schedule order (peel_relax.inc mode 2), or nullptr
     const uint32_t *sched_pull;   // [nframes][m][4] pairs: level of the step, two pulled accumulators (slot | coef << 24), spare (peel_relax.inc mode 2)
     int pairs;                // the schedules' levels come in groups of two (first / second half): one barrier per group, second halves pull
+    int t2_pieces;            // tier 2: consecutive pieces of a frame per work item (the set-up is shared); must divide nslices
+    int t2_force;             // ... also when the list is short (tests; by default short lists keep one piece per item)
     int xl_setup;             // level-phase lists translated (check -> accumulator address) at set-up instead of inside every level
     int enc_group;            // encode: the grouped static schedule (DevCode::encg_*: levels collapsed offline, steps pull in-group accumulators)
     int *err;                 // pinned host word (ldpc_amd_ctx::dev_err_host): a kernel whose assumptions do not hold reports here
@@ -699,6 +701,9 @@ __device__ __forceinline__ void stream_store16(uint8_t *p, const U4 &v)
 // PERSIST (encoder only: ldpc_scatter_static_kernel): a workgroup encodes many (frame, slice) items, and everything its LDS holds that
 // depends on the CODE alone -- multiply tables, the schedule's tables, the level phase's lists -- is set up by the first item (warm = false)
 // and kept; a warm item zeroes its accumulators and starts streaming.
+// WARM without PERSIST (decoder, tier 2: ldpc_scatter_big_kernel with several pieces per work item): the item before was another piece of
+// the SAME frame -- everything the set-up builds from the frame's schedule and erasure flags (step tables, check -> slot table, row kinds,
+// translated lists, pull records) is in place; only the accumulators and the row counter start over.
 template <int LPR, int R, bool NT, bool INPLACE, int WPE = 4, bool PERSIST = false, bool WARM = false>
 __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned char *smem, const int64_t f, const int sl)
 {
@@ -761,13 +766,13 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
 #pragma unroll
     for (int u = 0; u < SPT; u++) {
         const int s = tid + u * nthr;
-        stp[u] = (s < nsteps && !(PERSIST && warm)) ? gs[s] : 0u;
-        siv[u] = (s < nsteps && !(PERSIST && warm)) ? (uint32_t)gic[s] : 0u;
+        stp[u] = (s < nsteps && !warm) ? gs[s] : 0u;
+        siv[u] = (s < nsteps && !warm) ? (uint32_t)gic[s] : 0u;
     }
 #pragma unroll
     for (int u = 0; u < EPT; u++) {
         const int j = tid + u * nthr;
-        erv[u] = (j < n) ? (erf ? (uint32_t)erf[j] : (j >= a.in_rows ? 1u : 0u)) : 0u;
+        erv[u] = (j < n && !warm) ? (erf ? (uint32_t)erf[j] : (j >= a.in_rows ? 1u : 0u)) : 0u;
     }
     // The column lists of the symbols solved in phase B go to the LDS left over behind the accumulators of this
     // frame (nsteps of nslots used), so that phase B issues no global load: a load behind the phase's row stores
@@ -786,14 +791,14 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     for (int u = 0; u < SPT; u++) {
         const int s = tid + u * nthr;
         prc[u][0] = prc[u][1] = prc[u][2] = 0xFFFFFFFFu;
-        if (pairs_f && s < nsteps) {
+        if (pairs_f && s < nsteps && !warm) {
             const uint32_t *r_ = gpl + ((size_t)f * cd.m + s) * 4;
             prc[u][0] = r_[0]; prc[u][1] = r_[1]; prc[u][2] = r_[2];
         }
     }
     constexpr int LPT = 2;                      // list words per thread held in registers
     uint32_t lw[LPT];
-    if (lds_lists) {
+    if (lds_lists && !warm) {
 #pragma unroll
         for (int u = 0; u < LPT; u++) {
             const int e = tid + u * nthr;
@@ -808,7 +813,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
             }
         }
     }
-    if (!(PERSIST && warm)) {
+    if (!warm) {
     for (int i = tid; i < 2048; i += nthr) mt[i] = c_mul3[i];
 #ifdef LDPC_AMD_MLDBG
     for (int i = tid; i <= nlev; i += nthr) lvlend[i] = (uint16_t)min((int)gle[i], nsteps);
@@ -816,13 +821,13 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     for (int i = tid; i <= nlev; i += nthr) lvlend[i] = gle[i];
 #endif
     }
-    if (!is_static)   // (the encoder's lists are in slot form already: it has no check -> slot table)
+    if (!is_static && !warm)   // (the encoder's lists are in slot form already: it has no check -> slot table)
         for (int i = tid; i < (cd.m + 1) / 2; i += nthr) reinterpret_cast<uint32_t *>(soc)[i] = 0xFFFFFFFFu;
-    if (tid < 2) reinterpret_cast<int *>(smem + a.lds_rowctr)[tid] = 0;   // [0] row-batch counter of the streaming phase, [1] received rows
+    if (tid < (warm ? 1 : 2)) reinterpret_cast<int *>(smem + a.lds_rowctr)[tid] = 0;   // [0] row-batch counter of the streaming phase, [1] received rows
     for (int i = tid; i < nsteps * LPR; i += nthr) reinterpret_cast<U4 *>(acc)[i] = U4{0, 0, 0, 0};
     // row kinds: 1 received, 2 erased and never solved (written as 0), 0 erased and solved in phase B (set below)
     // (PERSIST: the encoder's source rows are all received -- its stream does not consult the table, whose place the lists of the level phase keep)
-    if (!PERSIST) {
+    if (!PERSIST && !warm) {
 #pragma unroll
     for (int u = 0; u < EPT; u++) {
         const int j = tid + u * nthr;
@@ -845,7 +850,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         plist[2 * s] = p0 == 0xFFFFFFFFu ? p0 : (((uint32_t)kAccOff + (p0 & 0x00FFFFFFu) * (uint32_t)B) | (p0 & 0xFF000000u));
         plist[2 * s + 1] = p1 == 0xFFFFFFFFu ? p1 : (((uint32_t)kAccOff + (p1 & 0x00FFFFFFu) * (uint32_t)B) | (p1 & 0xFF000000u));
     };
-    if (!(PERSIST && warm)) {
+    if (!warm) {
 #pragma unroll
     for (int u = 0; u < SPT; u++) {
         const int s = tid + u * nthr;
@@ -857,7 +862,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
         if (pairs_f) { const uint32_t *r_ = gpl + ((size_t)f * cd.m + s) * 4; put_pull(s, r_[0], r_[1], r_[2]); }
     }
     }
-    if (lds_lists) {
+    if (lds_lists && !warm) {
         // The lists go to LDS TRANSLATED (check -> LDS address of the step's accumulator slice | coef << 24, the form the turns of
         // `scatter` consume; the list's own step left out): the two dependent look-ups of the translation then happen once, here,
         // for all steps at a time, instead of inside every level's chain of LDS round trips (round 4).
@@ -1201,7 +1206,7 @@ __device__ __forceinline__ void scatter_frame(const ScatterArgs &a, unsigned cha
     const uint8_t *g_coef = smem + a.lds_soc + 2 * gent2;
     const uint16_t *g_off = reinterpret_cast<const uint16_t *>(smem + a.lds_soc + 3 * gent2);
     const uint8_t *g_np = smem + a.lds_soc + 3 * gent2 + 2 * ((cd.m + 8) & ~7);
-    if (PERSIST && warm) {
+    if (is_static && warm) {
         // (the lists are in place since the workgroup's first item)
     } else if (grouped) {
         uint16_t *ws = reinterpret_cast<uint16_t *>(smem + a.lds_soc);
@@ -1406,7 +1411,13 @@ __global__ __launch_bounds__(1024, WPE) void ldpc_scatter_big_kernel(ScatterArgs
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // work items (frame, slice) are handed out through a device counter, first come first served: their cost varies with the
     // frame's steps and levels, and with ~50 items per workgroup a fixed stride leaves the slowest workgroup a few items behind
-    const int items = a.big_list[0] * a.nslices;
+    // A work item is t2_pieces consecutive pieces of ONE frame (1, 2 or all of them): the first sets the frame's tables up, the others find
+    // them in place (scatter_frame<..., WARM>) -- the set-up was 9.7 % of a tier-2 workgroup's time on the cfg 3 batch, once per piece.
+    // (few frames in the list -- the (4080,3060) batch has four -- keep one piece per item: the kernel then lasts one item, not one frame)
+    int P = a.t2_pieces > 1 ? a.t2_pieces : 1;
+    while (P > 1 && !a.t2_force && (int64_t)a.big_list[0] * (a.nslices / P) < (int64_t)8 * gridDim.x) P >>= 1;
+    const int G = a.nslices / P;
+    const int items = a.big_list[0] * G;
     int *slot = reinterpret_cast<int *>(smem + a.lds_rowctr) + 2;   // (ints 0 / 1 of the region are re-initialised by every frame)
     for (;;) {
         __syncthreads();
@@ -1414,7 +1425,13 @@ __global__ __launch_bounds__(1024, WPE) void ldpc_scatter_big_kernel(ScatterArgs
         __syncthreads();
         const int it = *slot;
         if (it >= items) break;
-        scatter_frame<LPR, R, NT, INPLACE, WPE>(a, smem, a.big_list[2 + it / a.nslices], (int)(it % a.nslices));
+        const int64_t f = a.big_list[2 + it / G];
+        const int p0 = (it % G) * P;
+        scatter_frame<LPR, R, NT, INPLACE, WPE>(a, smem, f, p0);
+        for (int q = 1; q < P; q++) {
+            __syncthreads();   // the last level of the piece before is through with the accumulators
+            scatter_frame<LPR, R, NT, INPLACE, WPE, false, true>(a, smem, f, p0 + q);
+        }
     }
 }
 
@@ -1817,6 +1834,11 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
     if (p.two_tier && big_list && !(sa.dbg & 32768)) {
         sa.tcap = sa.code.m; sa.nslots = sa.code.m; sa.big_list = big_list;
         scatter_set_lds(sa, p, sa.code.m);
+        {   // pieces of a frame per work item (SCATTER_T2P; the list modes of the stream rebuild their row list per piece: one piece)
+            int tp = kn.scatter_dyn <= 1 ? std::max(1, kn.scatter_t2p) : 1;
+            while (tp > 1 && (sa.nslices % tp) != 0) tp >>= 1;
+            sa.t2_pieces = tp; sa.t2_force = kn.scatter_t2p_force;
+        }
         const dim3 g2((unsigned)std::min<int64_t>(sa.nframes * sa.nslices, ctx->sm_count));
         // tier 2 runs one workgroup per CU (4 waves per SIMD, 128 VGPRs each): more row pieces in flight per lane group make up
         // for part of the missing occupancy.  Round 2: two / three / four pieces 4.50 / 4.28 / 4.24 ms on cfg 3 (four shipped, 160 B
@@ -1847,6 +1869,7 @@ static int launch_scatter_lpr(ldpc_amd_ctx *ctx, const ScatterPlan &p, ScatterAr
             ScatterPlan p2 = p;
             p2.lpr = 8; p2.nslices = sa.S / 128; p2.lds2 = sa.code.m * 128 + tail_b;
             sa.nslices = p2.nslices;
+            while (sa.t2_pieces > 1 && (sa.nslices % sa.t2_pieces) != 0) sa.t2_pieces >>= 1;
             scatter_set_lds(sa, p2, sa.code.m);
             const dim3 g3((unsigned)std::min<int64_t>(sa.nframes * sa.nslices, (int64_t)ctx->sm_count * 2));
             ctx->prof_names[LDPC_AMD_PROF_APPLY_TIER2] = std::string("ldpc_scatter_big_kernel<8, 2, ") + (nt ? "true" : "false") + ", " + (ip ? "true" : "false") + ", 8>";

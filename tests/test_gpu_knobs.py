@@ -21,6 +21,7 @@ KNOBS = [
     ("LDPC_AMD_SCATTER_T2B", ["128"]),
     ("LDPC_AMD_SCATTER_XL", ["0"]),
     ("LDPC_AMD_SCATTER_PAIRS", ["0"]),
+    ("LDPC_AMD_SCATTER_T2P", ["1", "4"]),
     ("LDPC_AMD_SCATTER_LISTS", ["1"]),
     ("LDPC_AMD_SCATTER_NT", ["0"]),
     ("LDPC_AMD_SCATTER_XCD", ["0"]),

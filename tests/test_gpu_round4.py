@@ -207,3 +207,49 @@ def test_relaxation_equals_the_serial_loop_and_the_oracle(oracle, S):
             else:
                 o, _, it, info, rc = oc.decode_packets(symw[f], eraw[f], do_ml=0)
                 assert np.array_equal(out[0][f], o) and out[1][f] == it and out[2][f] == info[0]
+
+
+# ---- tier 2 of the packet kernel: several pieces of a frame per work item (SCATTER_T2P), the frame's set-up shared ---------------------
+def test_tier2_pieces_per_item_equal_one_piece_per_item_and_the_oracle(oracle):
+    """Bursty frames of BASELINE cfg 3 at S = 1024 (most have more steps than tier 1 holds; some reach the ML stage, some stay
+    rank deficient): 1, 2 and 4 pieces of a frame per tier-2 work item -- the later pieces find the frame's tables in place -- must
+    return the same bytes and status words, with plain and paired levels, and the oracle's on spot-checked
+    frames (Matlab/My_LDPC_HybridML_NonBinary_Erasure_Decoder.m:13-129)."""
+    code = codes.load_builtin(1)
+    oc = oracle.OracleCode(code)
+    with api.Context(0) as ctx:
+        h = ctx.load_builtin_code(1, codes.DEFAULT_COEF_SEED[1])
+        F, S = 40, 1024
+        src = synth.source(4242, 0, F, code.k, S)
+        cw = ctx.encode(h, src)
+        era = synth.erasures_bursty(4243, 0, 3 * F, code.n, 0.13, 0.8, 10.0)
+        era = np.ascontiguousarray(era[era.sum(axis=1) < code.n - code.k][:F])
+        assert era.shape[0] == F and (era.sum(axis=1) > 300).sum() >= 10
+        sym = cw.copy()
+        sym[era.astype(bool)] = 0x5A
+        ctx.configure("SCATTER_T2P_FORCE", "1")
+        try:
+            ref = None
+            for pairs in ("1", "0"):
+                ctx.configure("SCATTER_PAIRS", pairs)
+                for tp in ("1", "2", "4"):
+                    ctx.configure("SCATTER_T2P", tp)
+                    out, sw, res, st = ctx.decode(h, sym, era)
+                    if ref is None:
+                        ref = (out, sw, res, st)
+                        assert (st >= 1).sum() >= 3, np.bincount(st)
+                        for f in (0, 7, F - 1, int(np.flatnonzero(st >= 1)[0])):
+                            o_out, _, o_it, info, rc = oc.decode_packets(sym[f], era[f])
+                            assert np.array_equal(out[f], o_out) and sw[f] == o_it, f
+                    else:
+                        assert np.array_equal(out, ref[0]) and np.array_equal(st, ref[3]) and np.array_equal(sw, ref[1]), (pairs, tp)
+            for tp in ("2", "4"):   # list modes of the stream rebuild their row list per piece: they keep one piece per item
+                ctx.configure("SCATTER_T2P", tp)
+                for dyn in ("0", "2", "3", "4"):
+                    ctx.configure("SCATTER_DYN", dyn)
+                    out, sw, res, st = ctx.decode(h, sym, era)
+                    assert np.array_equal(out, ref[0]) and np.array_equal(st, ref[3]), (tp, dyn)
+                ctx.configure("SCATTER_DYN", None)
+        finally:
+            for k_ in ("SCATTER_T2P_FORCE", "SCATTER_T2P", "SCATTER_PAIRS", "SCATTER_DYN"):
+                ctx.configure(k_, None)
