@@ -332,6 +332,8 @@ class Gpu:
         for _ in range(warmup):
             ctx.decode(h, sym, era, out=out, sweeps=sw, residual=res, status=st)
             ctx.synchronize()   # (untimed) the library sizes its ML schedule arena from the demand of the calls already finished
+        if after_steps and warmup > 0 and self.world > 1:
+            after_steps(out, sw, res, st)   # (untimed) the collective's first call sets up its communicator and loads its kernels
         ctx.get_profile()
         ctx.set_profiling(True)
         self.barrier()
