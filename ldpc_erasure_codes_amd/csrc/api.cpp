@@ -121,6 +121,7 @@ static const KnobDesc kKnobs[] = {
     LDPC_KNOB_INT("RS_VW", rs_vw, x == 0 || x == 1 || x == 2 || x == 4),
     LDPC_KNOB_INT("HOST_PIPELINE", host_pipeline, x == 0 || x == 1),
     LDPC_KNOB_INT("FPGA_CHUNK", fpga_chunk, x >= 1),
+    LDPC_KNOB_INT("CHUNK_S1", chunk_s1, x >= 1024 && x <= (1ll << 20)),
 };
 #undef LDPC_KNOB_INT
 }  // namespace

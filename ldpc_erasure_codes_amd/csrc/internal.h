@@ -144,6 +144,8 @@ struct Knobs {
     int rs_vw = 0;               // RS_VW: dwords per lane of the packet RS kernel (0 = auto = 1; 2 and 4 where S allows)
     int host_pipeline = 1;       // HOST_PIPELINE: chunked upload / compute / download pipeline for large host buffers
     long fpga_chunk = 65536;     // FPGA_CHUNK: frames per chunk of the streamed FPGA-harness run
+    long chunk_s1 = 65536;       // CHUNK_S1: S = 1 decode -- frames per launch of a long batch (packets always 16384: their schedules are per-frame workspaces).
+                                 // Every launch drains the device once: 65536 (4080,3060) frames 2.233 ms in four launches, 2.082 in one (tools/ab_chunk_s1.py)
 };
 // key: "LDPC_AMD_SCATTER_B" or "SCATTER_B" (case-insensitive); value nullptr or "" restores the default.  0 = OK, -1 = unknown key / bad value.
 int knob_set(Knobs &k, const char *key, const char *value);

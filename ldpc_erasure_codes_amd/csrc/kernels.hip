@@ -1915,7 +1915,7 @@ int launch_decode(ldpc_amd_ctx *ctx, const DecodeArgs &d)
     if (d.max_sweeps < 1) return set_error(ctx, LDPC_AMD_EINVAL, "max_sweeps must be >= 1");
 
     // bound the per-call workspaces: long batches are processed in chunks of frames
-    const int64_t kChunk = 16384;
+    const int64_t kChunk = fused ? (int64_t)ctx->knobs.chunk_s1 : 16384;
     if (d.nframes > kChunk) {
         for (int64_t f0 = 0; f0 < d.nframes; f0 += kChunk) {
             DecodeArgs c = d;

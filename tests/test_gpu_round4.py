@@ -253,3 +253,35 @@ def test_tier2_pieces_per_item_equal_one_piece_per_item_and_the_oracle(oracle):
         finally:
             for k_ in ("SCATTER_T2P_FORCE", "SCATTER_T2P", "SCATTER_PAIRS", "SCATTER_DYN"):
                 ctx.configure(k_, None)
+
+
+# ---- long S = 1 batches: frames per launch (CHUNK_S1) ------------------------------------------------------------------------------
+def test_long_s1_batch_is_the_same_in_one_launch_and_in_chunks(oracle):
+    """Frames are independent (one decoder call per frame in the reference, Matlab/ErasureCodes_NonBinaryLDPCSim.m:218), so a long
+    S = 1 batch decoded in one launch, in chunks with a ragged last one (CHUNK_S1 = 1024, 2048) and frame by frame by the oracle
+    must agree on every byte and status word -- with frames in the batch that reach the ML stage and that it cannot finish."""
+    code = codes.load_builtin(1)
+    oc = oracle.OracleCode(code)
+    F = 5000
+    with api.Context(0) as ctx:
+        h = ctx.load_builtin_code(1, codes.DEFAULT_COEF_SEED[1])
+        src = synth.source(77, 0, F, code.k, 1)
+        cw = ctx.encode(h, src[:, :, 0])
+        era = synth.erasures_uniform(78, 0, F, code.n, 0.10)
+        era[1000:1400] = synth.erasures_uniform(79, 0, 400, code.n, 0.21)     # frames for the ML stage, across the 1024-frame border
+        era[4990:] = synth.erasures_uniform(80, 0, 10, code.n, 0.26)          # more erasures than checks: cannot be decoded
+        sym = cw.copy()
+        sym[era.astype(bool)] = 0x3C
+        ctx.configure("CHUNK_S1", "1048576")
+        one = ctx.decode(h, sym, era)
+        assert set(one[3].tolist()) >= {0, 1} and one[3].max() >= 2
+        for chunk in ("1024", "2048", None):
+            ctx.configure("CHUNK_S1", chunk)
+            got = ctx.decode(h, sym, era)
+            for x, y, what in zip(one, got, ("out", "sweeps", "residual", "status")):
+                assert np.array_equal(x, y), (chunk, what)
+        for f in (0, 1023, 1024, 1100, 2047, 2048, 4095, 4096, 4995, F - 1):
+            o = oc.decode_batch_s1(sym[f:f + 1], era[f:f + 1])
+            assert np.array_equal(one[0][f], o[0][0]) and one[1][f] == o[1][0] and one[2][f] == o[2][0] and one[3][f] == o[3][0], f
+        with pytest.raises(api.LdpcAmdError):
+            ctx.configure("CHUNK_S1", "100")
